@@ -1,0 +1,134 @@
+/*
+ * sbg_hip.h -- C ABI of libsbg_hip.so, the MI355X (gfx950) hot path of the
+ * Style-Big-GAN custom-op layer.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers, sizes and a
+ * hipStream_t (passed as void*), never blocks the host, never allocates, and
+ * returns 0 on success or a non-zero sbg_status; sbg_last_error() returns a
+ * thread-local human readable message for the last failing call of the calling
+ * thread.  Inputs are borrowed and never written; outputs are caller-allocated.
+ * Entry points are re-entrant (autograd worker threads call them concurrently).
+ *
+ * Each declaration cites the reference interface it replaces
+ * (paths relative to the reference checkout).
+ */
+#ifndef SBG_HIP_H
+#define SBG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sbg_stream_t;            /* hipStream_t */
+
+enum sbg_status {
+    SBG_OK = 0,
+    SBG_ERR_INVALID = 1,               /* argument validation failed (reference: TORCH_CHECK) */
+    SBG_ERR_UNSUPPORTED = 2,           /* valid but not implemented by this build            */
+    SBG_ERR_LAUNCH = 3                 /* hipLaunchKernel / runtime error                     */
+};
+
+enum sbg_dtype { SBG_F32 = 0, SBG_F16 = 1, SBG_BF16 = 2 };
+
+/* activation ids follow the reference's `cuda_idx`
+ * (stylegan2ada/torch_utils/ops/bias_act.py:23-33). */
+enum sbg_act {
+    SBG_ACT_LINEAR = 1, SBG_ACT_RELU = 2, SBG_ACT_LRELU = 3, SBG_ACT_TANH = 4, SBG_ACT_SIGMOID = 5,
+    SBG_ACT_ELU = 6, SBG_ACT_SELU = 7, SBG_ACT_SOFTPLUS = 8, SBG_ACT_SWISH = 9
+};
+
+int         sbg_version(void);
+const char* sbg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * bias_act: y = clamp(act(x + b[(i / stepB) % sizeB]) * gain)  and its 1st / 2nd derivative forms.
+ * Replaces the pybind entry `bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)`
+ * (stylegan2ada/torch_utils/ops/bias_act.cpp:32-90) with the fields of `bias_act_kernel_params`
+ * (stylegan2ada/torch_utils/ops/bias_act.h:12-31) minus the launch-tuning ones.
+ * NULL pointer == "absent" (the reference passes an empty tensor).  All tensors share x's dense
+ * layout; `dtype` applies to x, b, xref, yref, dy, y.  clamp < 0 disables clamping. */
+int sbg_bias_act(const void* x, const void* b, const void* xref, const void* yref, const void* dy,
+                 void* y, int dtype, int grad, int act, float alpha, float gain, float clamp,
+                 int64_t sizeX, int sizeB, int64_t stepB, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * upfirdn2d: pad -> zero-insert upsample -> 2-D FIR -> decimate.
+ * Replaces the pybind entry `upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1,
+ * flip, gain)` (stylegan2ada/torch_utils/ops/upfirdn2d.cpp:16-94) with the fields of
+ * `upfirdn2d_kernel_params` (stylegan2ada/torch_utils/ops/upfirdn2d.h:14-40).
+ * Sizes/strides are [W, H, C, N] in elements like the reference's int4 fields; the filter is
+ * float32 [fh, fw] with element strides; padx1/pady1 are implied by the output size. */
+typedef struct sbg_upfirdn2d_params {
+    const void*  x;
+    const float* f;
+    void*        y;
+    int dtype;
+    int upx, upy, downx, downy, padx0, pady0;
+    int flip;
+    float gain;
+    int     inSize[4];      int64_t inStride[4];
+    int     filterSize[2];  int     filterStride[2];      /* [W, H] */
+    int     outSize[4];     int64_t outStride[4];
+} sbg_upfirdn2d_params;
+int sbg_upfirdn2d(const sbg_upfirdn2d_params* p, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (channels-last activations).
+ * Replaces the aten/cuDNN calls behind `conv2d_gradfix.conv2d / conv_transpose2d`
+ * (stylegan2ada/torch_utils/ops/conv2d_gradfix.py:35-45,107-118): forward, data-gradient and the
+ * four sub-pixel phases of a stride-2 transposed convolution are all expressed as
+ *
+ *   y[n, oy*ysh + yoh, ox*ysw + yow, co] (+)= sum_{t < ntaps} sum_{ci}
+ *        x[n, oy*stride + dy[t], ox*stride + dx[t], ci] * w[wslab[t]][co][ci]
+ *
+ * over the launch's output grid OH x OW (out-of-range input pixels read as zero).
+ * x: [N, IH, IW, Cin] channel-minor (Cin % 8 == 0, pixel stride xs_w etc. in elements),
+ * w: packed [nslabs][Cout][Cin] (same dtype as x), y: channel-minor, dtype `ydtype`.
+ * Optional epilogue: y = y * oscale[n*Cout + co] (fp32, per sample & channel), applied before
+ * the store; `accumulate` adds into the existing y (fp32 y only). */
+#define SBG_MAX_TAPS 16
+typedef struct sbg_conv_params {
+    const void* x; const void* w; void* y;
+    const float* oscale;
+    int xdtype, ydtype;
+    int N, IH, IW, Cin, Cout, OH, OW;
+    int64_t xs_n, xs_h, xs_w;
+    int64_t ys_n, ys_h, ys_w;
+    int64_t ws_slab, ws_co;
+    int stride;
+    int ntaps;
+    int tap_dy[SBG_MAX_TAPS], tap_dx[SBG_MAX_TAPS], tap_slab[SBG_MAX_TAPS];
+    int accumulate;
+} sbg_conv_params;
+int sbg_conv2d_igemm(const sbg_conv_params* p, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight gradient (replaces `aten::cudnn_convolution_backward_weight` /
+ * `..._transpose_backward_weight`, conv2d_gradfix.py:140-147):
+ *
+ *   out[t][ca][cb] = sum_{n, py, px} a[n, py, px, ca] * b[n, py*stride + dy[t], px*stride + dx[t], cb]
+ *
+ * a: [N, PH, PW, Ca], b: [N, BH, BW, Cb], both channel-minor with Ca % 8 == Cb % 8 == 0, same dtype;
+ * out: fp32 [ntaps][Ca][Cb].  The pixel sum is split over `nsplit` workgroups that write fp32
+ * partial slabs into `workspace` (>= sbg_conv2d_wgrad_workspace() bytes) and a second kernel reduces
+ * them in a fixed order (bitwise reproducible). `accumulate` adds into the existing out. */
+typedef struct sbg_wgrad_params {
+    const void* a; const void* b; float* out; void* workspace;
+    int dtype;
+    int N, PH, PW, Ca, BH, BW, Cb;
+    int64_t as_n, as_h, as_w;
+    int64_t bs_n, bs_h, bs_w;
+    int stride;
+    int ntaps;
+    int tap_dy[SBG_MAX_TAPS], tap_dx[SBG_MAX_TAPS];
+    int accumulate;
+} sbg_wgrad_params;
+int64_t sbg_conv2d_wgrad_workspace(const sbg_wgrad_params* p);
+int     sbg_conv2d_wgrad(const sbg_wgrad_params* p, sbg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBG_HIP_H */

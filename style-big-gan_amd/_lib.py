@@ -1,0 +1,126 @@
+"""ctypes binding of libsbg_hip.so (the C ABI declared in include/sbg_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsbg_hip.so")
+
+SBG_F32, SBG_F16, SBG_BF16 = 0, 1, 2
+SBG_MAX_TAPS = 16
+
+_DTYPES = {torch.float32: SBG_F32, torch.float16: SBG_F16, torch.bfloat16: SBG_BF16}
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise RuntimeError(f"style_big_gan_amd: unsupported dtype {dtype} (float32 / float16 / bfloat16 only)")
+
+
+class UpfirdnParams(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("f", ctypes.c_void_p), ("y", ctypes.c_void_p),
+        ("dtype", ctypes.c_int),
+        ("upx", ctypes.c_int), ("upy", ctypes.c_int), ("downx", ctypes.c_int), ("downy", ctypes.c_int),
+        ("padx0", ctypes.c_int), ("pady0", ctypes.c_int),
+        ("flip", ctypes.c_int), ("gain", ctypes.c_float),
+        ("inSize", ctypes.c_int * 4), ("inStride", ctypes.c_int64 * 4),
+        ("filterSize", ctypes.c_int * 2), ("filterStride", ctypes.c_int * 2),
+        ("outSize", ctypes.c_int * 4), ("outStride", ctypes.c_int64 * 4),
+    ]
+
+
+class ConvParams(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("oscale", ctypes.c_void_p),
+        ("xdtype", ctypes.c_int), ("ydtype", ctypes.c_int),
+        ("N", ctypes.c_int), ("IH", ctypes.c_int), ("IW", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
+        ("OH", ctypes.c_int), ("OW", ctypes.c_int),
+        ("xs_n", ctypes.c_int64), ("xs_h", ctypes.c_int64), ("xs_w", ctypes.c_int64),
+        ("ys_n", ctypes.c_int64), ("ys_h", ctypes.c_int64), ("ys_w", ctypes.c_int64),
+        ("ws_slab", ctypes.c_int64), ("ws_co", ctypes.c_int64),
+        ("stride", ctypes.c_int), ("ntaps", ctypes.c_int),
+        ("tap_dy", ctypes.c_int * SBG_MAX_TAPS), ("tap_dx", ctypes.c_int * SBG_MAX_TAPS), ("tap_slab", ctypes.c_int * SBG_MAX_TAPS),
+        ("accumulate", ctypes.c_int),
+    ]
+
+
+class WgradParams(ctypes.Structure):
+    _fields_ = [
+        ("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("out", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+        ("dtype", ctypes.c_int),
+        ("N", ctypes.c_int), ("PH", ctypes.c_int), ("PW", ctypes.c_int), ("Ca", ctypes.c_int),
+        ("BH", ctypes.c_int), ("BW", ctypes.c_int), ("Cb", ctypes.c_int),
+        ("as_n", ctypes.c_int64), ("as_h", ctypes.c_int64), ("as_w", ctypes.c_int64),
+        ("bs_n", ctypes.c_int64), ("bs_h", ctypes.c_int64), ("bs_w", ctypes.c_int64),
+        ("stride", ctypes.c_int), ("ntaps", ctypes.c_int),
+        ("tap_dy", ctypes.c_int * SBG_MAX_TAPS), ("tap_dx", ctypes.c_int * SBG_MAX_TAPS),
+        ("accumulate", ctypes.c_int),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+# every symbol include/sbg_hip.h declares: (name, restype, argtypes)
+_c = ctypes
+SYMBOLS = [
+    ("sbg_version", _c.c_int, []),
+    ("sbg_last_error", _c.c_char_p, []),
+    ("sbg_bias_act", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
+                                                   _c.c_int64, _c.c_int, _c.c_int64, _c.c_void_p]),
+    ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
+    ("sbg_conv2d_igemm", _c.c_int, [_c.POINTER(ConvParams), _c.c_void_p]),
+    ("sbg_conv2d_wgrad_workspace", _c.c_int64, [_c.POINTER(WgradParams)]),
+    ("sbg_conv2d_wgrad", _c.c_int, [_c.POINTER(WgradParams), _c.c_void_p]),
+]
+
+
+def load():
+    """Load libsbg_hip.so once; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"style_big_gan_amd: HIP extension {LIB_PATH} not found. Build it with "
+                f"`make -C {os.path.join(_HERE, 'csrc')}` or `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().sbg_last_error()
+        raise RuntimeError(f"{what} failed (status {status}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_cuda(t, what):
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            f"{what}: tensor is on '{t.device}'. style_big_gan_amd ops run only as HIP kernels on a ROCm device "
+            "(device type 'cuda'); there is no CPU path in the product (the CPU restatement lives in oracle/ and is test-only).")

@@ -1,0 +1,262 @@
+// conv_igemm.hip -- implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_16x16x32_{bf16,f16}).
+//
+// One kernel serves forward convolution, data gradient (a convolution with flipped / transposed weights) and each of
+// the four sub-pixel phases of a stride-2 transposed convolution: the host describes the launch as a tap list
+//     y[n, oy*ysh + .., ox*ysw + .., co] (+)= sum_t sum_ci x[n, oy*stride + dy[t], ox*stride + dx[t], ci] * w[slab[t]][co][ci]
+// (see include/sbg_hip.h).  This replaces the cuDNN calls behind conv2d_gradfix.conv2d / conv_transpose2d
+// (stylegan2ada/torch_utils/ops/conv2d_gradfix.py:107-137).
+//
+// GEMM view: D[co][pixel] = sum_k W[co][k] * X[k][pixel], k = (tap, ci).  The weights are the MFMA A operand and the
+// gathered activations the B operand, so a lane ends up holding 4 consecutive output channels of one pixel -- a
+// contiguous 8-B (bf16) / 16-B (fp32) channel-minor store.
+//
+// Workgroup = 256 lanes = 4 waves (64-wide), tile BC output channels x BP output pixels, K-step 32 (one MFMA deep).
+// Activations are channel-minor, so for a fixed tap the 32-channel slice of a pixel is 64 contiguous bytes: every lane
+// stages 16-B pieces global -> VGPR -> LDS (issue early / write late, 2 LDS stages, one barrier per K-step).
+// LDS image per operand: [k-group g = 0..3][row][8 x 16-bit] (16-B cells).  A ds_read_b128 of MFMA fragments touches 16
+// rows that are distinct mod 16 -> 16 distinct 16-B slots of the 256-B bank row: conflict-free; the staging writes put 8
+// consecutive rows of one k-group in each 8-lane store group: 128 contiguous bytes, conflict-free.
+#include "sbg_common.h"
+
+namespace {
+
+struct bf16_mfma { static constexpr int dtype = SBG_BF16; };
+struct f16_mfma  { static constexpr int dtype = SBG_F16;  };
+
+template <class MF> struct Mfma;
+template <> struct Mfma<bf16_mfma> {
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short cvt(float v) { return f32_to_bf16_bits(v); }
+};
+template <> struct Mfma<f16_mfma> {
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short cvt(float v) { return f32_to_f16_bits(v); }
+};
+
+struct ConvArgs {
+    const unsigned short* x; const unsigned short* w; void* y; const float* oscale;
+    int ydtype;
+    int N, IH, IW, Cin, Cout, OH, OW;
+    int64_t xs_n, xs_h, xs_w, ys_n, ys_h, ys_w, ws_slab, ws_co;
+    int stride, ntaps;
+    int tap_dy[SBG_MAX_TAPS], tap_dx[SBG_MAX_TAPS], tap_slab[SBG_MAX_TAPS];
+    int accumulate;
+    int P;            // N * OH * OW output pixels of this launch
+    int ptiles, ctiles;
+};
+
+// lane -> (row within a 16-row staging group, k-group): 8 consecutive lanes share a k-group and walk 8 rows.
+static __device__ __forceinline__ int stage_row16(int lane) { return (lane & 7) | ((lane >> 5) << 3); }
+static __device__ __forceinline__ int stage_kgrp(int lane)  { return (lane >> 3) & 3; }
+
+template <class MF, int BC, int BP, int WGC, int WGP>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
+{
+    static_assert(WGC * WGP == 4, "4 waves per workgroup");
+    constexpr int WC = BC / WGC, WP = BP / WGP;        // wave tile
+    constexpr int TC = WC / 16,  TP = WP / 16;         // 16x16 MFMA tiles per wave
+    constexpr int RA = BC / 64,  RB = BP / 64;         // staging rows per lane (16 rows per wave-instruction, 4 waves)
+    static_assert(BC % 64 == 0 && BP % 64 == 0, "tile must be a multiple of 64");
+
+    // LDS: 2 stages x { A [4][BC] cells, B [4][BP] cells }, cell = 16 B.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int A_BYTES = 4 * BC * 16, B_BYTES = 4 * BP * 16, STAGE = A_BYTES + B_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (L2); give each XCD a contiguous run of tiles.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int ct = bid % p.ctiles, pt = bid / p.ctiles;
+    const int c0 = ct * BC, p0 = pt * BP;
+
+    // ---- per-lane staging coordinates -------------------------------------------------------------------------
+    const int srow = wave * 16 + stage_row16(lane), sg = stage_kgrp(lane);
+    // B operand rows = output pixels: decode (n, oy, ox) once.
+    int  b_iy0[RB], b_ix0[RB]; int64_t b_base[RB]; bool b_ok[RB];
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        const int pix = p0 + srow + 64 * i;
+        b_ok[i] = pix < p.P;
+        const int pp = b_ok[i] ? pix : 0;
+        const int ox = pp % p.OW, t = pp / p.OW, oy = t % p.OH, n = t / p.OH;
+        b_iy0[i] = oy * p.stride; b_ix0[i] = ox * p.stride; b_base[i] = (int64_t)n * p.xs_n;
+    }
+    // A operand rows = output channels.
+    int64_t a_off[RA]; bool a_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; i++) {
+        const int co = c0 + srow + 64 * i;
+        a_ok[i] = co < p.Cout;
+        a_off[i] = (int64_t)(a_ok[i] ? co : 0) * p.ws_co;
+    }
+
+    const int kchunks = (p.Cin + 31) >> 5;
+    const int nsteps = p.ntaps * kchunks;
+
+    short8_t ra[RA], rb[RB];
+    auto issue_loads = [&](int step) {
+        const int t = step / kchunks, ck = (step - t * kchunks) * 32 + sg * 8;
+        const bool kok = ck < p.Cin;
+        const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+        const unsigned short* wslab = p.w + (int64_t)p.tap_slab[t] * p.ws_slab + ck;
+#pragma unroll
+        for (int i = 0; i < RA; i++) {
+            short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kok && a_ok[i]) v = *reinterpret_cast<const short8_t*>(wslab + a_off[i]);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
+            const int iy = b_iy0[i] + dy, ix = b_ix0[i] + dx;
+            short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kok && b_ok[i] && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
+                v = *reinterpret_cast<const short8_t*>(p.x + b_base[i] + (int64_t)iy * p.xs_h + (int64_t)ix * p.xs_w + ck);
+            rb[i] = v;
+        }
+    };
+    auto write_stage = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE;
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < RA; i++) *reinterpret_cast<short8_t*>(sa + (sg * BC + srow + 64 * i) * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; i++) *reinterpret_cast<short8_t*>(sb + (sg * BP + srow + 64 * i) * 16) = rb[i];
+    };
+
+    // ---- MFMA coordinates ---------------------------------------------------------------------------------------
+    const int wc = (wave / WGP) * WC, wp = (wave % WGP) * WP;
+    const int fr = lane & 15, fg = lane >> 4;
+    float4_t acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; i++)
+#pragma unroll
+        for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0);
+    write_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; s++) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) issue_loads(s + 1);
+        const unsigned char* sa = smem + buf * STAGE;
+        const unsigned char* sb = sa + A_BYTES;
+        short8_t fa[TC], fb[TP];
+#pragma unroll
+        for (int i = 0; i < TC; i++) fa[i] = *reinterpret_cast<const short8_t*>(sa + (fg * BC + wc + 16 * i + fr) * 16);
+#pragma unroll
+        for (int j = 0; j < TP; j++) fb[j] = *reinterpret_cast<const short8_t*>(sb + (fg * BP + wp + 16 * j + fr) * 16);
+#pragma unroll
+        for (int i = 0; i < TC; i++)
+#pragma unroll
+            for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[i], fb[j], acc[i][j]);
+        if (s + 1 < nsteps) write_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels cbase + 4*fg + {0..3} of pixel (wp + 16 j + fr) ----------------------------
+#pragma unroll
+    for (int j = 0; j < TP; j++) {
+        const int pix = p0 + wp + 16 * j + fr;
+        if (pix >= p.P) continue;
+        const int ox = pix % p.OW, t = pix / p.OW, oy = t % p.OH, n = t / p.OH;
+        const int64_t yoff = (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
+#pragma unroll
+        for (int i = 0; i < TC; i++) {
+            const int co = c0 + wc + 16 * i + 4 * fg;
+            if (co >= p.Cout) continue;
+            float4_t v = acc[i][j];
+            if (p.oscale) {
+                const float* sc = p.oscale + (int64_t)n * p.Cout + co;
+#pragma unroll
+                for (int e = 0; e < 4; e++) if (co + e < p.Cout) v[e] *= sc[e];
+            }
+            const bool full = (co + 4 <= p.Cout);
+            if (p.ydtype == SBG_F32) {
+                float* dst = (float*)p.y + yoff + co;
+                if (full && ((((uintptr_t)dst) & 15) == 0)) {
+                    float4_t o = v;
+                    if (p.accumulate) { float4_t old = *reinterpret_cast<float4_t*>(dst); o += old; }
+                    *reinterpret_cast<float4_t*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) if (co + e < p.Cout) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
+                }
+            } else {
+                unsigned short* dst = (unsigned short*)p.y + yoff + co;
+                unsigned short h[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) h[e] = (p.ydtype == SBG_BF16) ? f32_to_bf16_bits(v[e]) : f32_to_f16_bits(v[e]);
+                if (full && ((((uintptr_t)dst) & 7) == 0)) {
+                    short4_t o = {(short)h[0], (short)h[1], (short)h[2], (short)h[3]};
+                    *reinterpret_cast<short4_t*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) if (co + e < p.Cout) dst[e] = h[e];
+                }
+            }
+        }
+    }
+}
+
+template <class MF, int BC, int BP, int WGC, int WGP>
+static int launch_conv(ConvArgs& a, hipStream_t stream)
+{
+    a.ptiles = (a.P + BP - 1) / BP;
+    a.ctiles = (a.Cout + BC - 1) / BC;
+    const int64_t nblk = (int64_t)a.ptiles * a.ctiles;
+    if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
+    constexpr int lds = 2 * (4 * BC * 16 + 4 * BP * 16);
+    auto kern = conv_igemm_kernel<MF, BC, BP, WGC, WGP>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
+
+template <class MF>
+static int dispatch_conv(ConvArgs& a, hipStream_t stream)
+{
+    // tile choice: few output channels -> pixel-heavy tile; otherwise 128 x 128.
+    if (a.Cout <= 64)  return launch_conv<MF, 64, 256, 1, 4>(a, stream);
+    return launch_conv<MF, 128, 128, 2, 2>(a, stream);
+}
+
+} // namespace
+
+extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
+{
+    SBG_CHECK(q && q->x && q->w && q->y, "conv2d_igemm: null pointer");
+    SBG_CHECK(q->xdtype == SBG_BF16 || q->xdtype == SBG_F16, "conv2d_igemm: x/w must be bf16 or f16 (fp32 inputs are split by the host)");
+    SBG_CHECK(q->ydtype == SBG_F32 || q->ydtype == SBG_BF16 || q->ydtype == SBG_F16, "conv2d_igemm: bad output dtype");
+    SBG_CHECK(q->N >= 0 && q->IH >= 1 && q->IW >= 1 && q->OH >= 1 && q->OW >= 1 && q->Cin >= 8 && q->Cout >= 1, "conv2d_igemm: bad sizes");
+    SBG_CHECK((q->Cin % 8) == 0, "conv2d_igemm: Cin must be a multiple of 8 (pad on the host)");
+    SBG_CHECK(q->ntaps >= 1 && q->ntaps <= SBG_MAX_TAPS, "conv2d_igemm: 1..%d taps", SBG_MAX_TAPS);
+    SBG_CHECK(q->stride >= 1, "conv2d_igemm: stride must be >= 1");
+    SBG_CHECK(!q->accumulate || q->ydtype == SBG_F32, "conv2d_igemm: accumulate needs an fp32 output");
+    SBG_CHECK(sbg_aligned16(q->x) && sbg_aligned16(q->w), "conv2d_igemm: x and w must be 16-byte aligned");
+    SBG_CHECK((q->xs_n % 8) == 0 && (q->xs_h % 8) == 0 && (q->xs_w % 8) == 0 && (q->ws_slab % 8) == 0 && (q->ws_co % 8) == 0,
+              "conv2d_igemm: pixel / row strides must be multiples of 8 elements");
+    const int64_t P = (int64_t)q->N * q->OH * q->OW;
+    SBG_CHECK(P <= INT32_MAX, "conv2d_igemm: too many output pixels");
+    if (P == 0) return SBG_OK;
+
+    ConvArgs a;
+    a.x = (const unsigned short*)q->x; a.w = (const unsigned short*)q->w; a.y = q->y; a.oscale = q->oscale;
+    a.ydtype = q->ydtype;
+    a.N = q->N; a.IH = q->IH; a.IW = q->IW; a.Cin = q->Cin; a.Cout = q->Cout; a.OH = q->OH; a.OW = q->OW;
+    a.xs_n = q->xs_n; a.xs_h = q->xs_h; a.xs_w = q->xs_w; a.ys_n = q->ys_n; a.ys_h = q->ys_h; a.ys_w = q->ys_w;
+    a.ws_slab = q->ws_slab; a.ws_co = q->ws_co;
+    a.stride = q->stride; a.ntaps = q->ntaps;
+    for (int t = 0; t < SBG_MAX_TAPS; t++) { a.tap_dy[t] = q->tap_dy[t]; a.tap_dx[t] = q->tap_dx[t]; a.tap_slab[t] = q->tap_slab[t]; }
+    a.accumulate = q->accumulate;
+    a.P = (int)P; a.ptiles = a.ctiles = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (q->xdtype == SBG_BF16) return dispatch_conv<bf16_mfma>(a, s);
+    return dispatch_conv<f16_mfma>(a, s);
+}

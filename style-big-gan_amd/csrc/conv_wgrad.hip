@@ -1,0 +1,306 @@
+// conv_wgrad.hip -- convolution weight gradient on the gfx950 matrix cores.
+//
+//   out[t][ca][cb] = sum_{n,py,px} a[n,py,px,ca] * b[n, py*stride + dy[t], px*stride + dx[t], cb]
+//
+// replaces aten::cudnn_convolution_backward_weight / ..._transpose_backward_weight
+// (stylegan2ada/torch_utils/ops/conv2d_gradfix.py:140-147).  `a` is the tensor living on the coarse grid (grad_output
+// for a forward conv, the input for a transposed conv), `b` the one on the fine grid.
+//
+// GEMM view per tap: D[ca][cb] = sum_pix A[ca][pix] * B[pix][cb]; the reduction index is the pixel, which is the SLOW
+// axis of both channel-minor operands, so both MFMA fragments are read from pixel-major LDS tiles with the hardware
+// transposing read ds_read_b64_tr_b16.  The k order inside a 32-pixel chunk is a free permutation (both operands use the
+// same one): 16-lane group g takes pixels {4g..4g+3} and {16+4g..16+4g+3}, which with a row stride of (channels*2 + 32)
+// bytes keeps each 32-lane half on 8 distinct 32-B bank slots (conflict-free).
+//
+// Workgroup = 256 lanes (2 x 2 waves), tile BCA x BCB channels for ALL taps of the launch (<= NT accumulator sets in
+// registers), walking its share of the pixel axis in 32-pixel chunks: the a-tile is staged once per chunk and re-used by
+// every tap, only the gathered b-tiles change.  The pixel axis is split over gridDim.z workgroups that write fp32
+// partial slabs; a second kernel sums the slabs in a fixed order (bitwise reproducible, no float atomics).
+#include "sbg_common.h"
+
+namespace {
+
+struct bf16_mfma {}; struct f16_mfma {};
+template <class MF> struct Mfma;
+template <> struct Mfma<bf16_mfma> {
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<f16_mfma> {
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+struct WgradArgs {
+    const unsigned short* a; const unsigned short* b; float* out; float* ws;
+    int N, PH, PW, Ca, BH, BW, Cb;
+    int64_t as_n, as_h, as_w, bs_n, bs_h, bs_w;
+    int stride, ntaps;
+    int tap_dy[SBG_MAX_TAPS], tap_dx[SBG_MAX_TAPS];
+    int accumulate;
+    int64_t P;              // N * PH * PW pixels on the coarse grid
+    int nchunks;            // ceil(P / 32)
+    int nsplit, chunks_per_split;
+    int atiles, btiles;
+    int tap0;               // first tap handled by this launch (out slab offset)
+    int ntaps_total;
+};
+
+typedef __attribute__((address_space(3))) short4_t* lds_s4_ptr;
+
+// transposing LDS read: lane (16-lane group, 4q+p) passes the address of row q, columns 4p..4p+3; lane i gets column i of
+// the 4 rows.
+static __device__ __forceinline__ short4_t lds_tr_read(const unsigned char* p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p));
+}
+
+template <class MF, int BCA, int BCB, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
+{
+    constexpr int WA = BCA / 2, WB = BCB / 2;          // wave tile (2 x 2 waves)
+    constexpr int TA = WA / 16, TB = WB / 16;
+    constexpr int RSA = BCA * 2 + 32, RSB = BCB * 2 + 32;   // LDS row strides (bytes), padded by 32 B
+    constexpr int A_BYTES = 32 * RSA, B_BYTES = 32 * RSB;
+    constexpr int CHA = BCA / 8, CHB = BCB / 8;        // 16-B chunks per pixel row
+    constexpr int LA = (32 * CHA) / 256, LB = (32 * CHB) / 256;   // staging loads per lane per tile
+    static_assert(LA >= 1 && LB >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + A_BYTES;                 // NT tiles
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ca0 = blockIdx.x * BCA, cb0 = blockIdx.y * BCB, split = blockIdx.z;
+    const int chunk_begin = split * p.chunks_per_split;
+    int chunk_end = chunk_begin + p.chunks_per_split;
+    if (chunk_end > p.nchunks) chunk_end = p.nchunks;
+
+    const int wa = (wave >> 1) * WA, wb = (wave & 1) * WB;
+    const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
+
+    float4_t acc[NT][TA][TB];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < TA; i++)
+#pragma unroll
+            for (int j = 0; j < TB; j++) acc[t][i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    short8_t ra[LA], rb[NT][LB];
+    auto issue_loads = [&](int chunk) {
+        const int64_t pix0 = (int64_t)chunk * 32;
+#pragma unroll
+        for (int l = 0; l < LA; l++) {
+            const int idx = tid + 256 * l, row = idx / CHA, ch = idx % CHA;
+            const int64_t pix = pix0 + row;
+            const int c = ca0 + ch * 8;
+            short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (pix < p.P && c < p.Ca) {
+                const int px = (int)(pix % p.PW); const int64_t r = pix / p.PW; const int py = (int)(r % p.PH); const int n = (int)(r / p.PH);
+                v = *reinterpret_cast<const short8_t*>(p.a + n * p.as_n + py * p.as_h + px * p.as_w + c);
+            }
+            ra[l] = v;
+        }
+#pragma unroll
+        for (int l = 0; l < LB; l++) {
+            const int idx = tid + 256 * l, row = idx / CHB, ch = idx % CHB;
+            const int64_t pix = pix0 + row;
+            const int c = cb0 + ch * 8;
+            const bool ok = pix < p.P && c < p.Cb;
+            int px = 0, py = 0, n = 0;
+            if (ok) { px = (int)(pix % p.PW); const int64_t r = pix / p.PW; py = (int)(r % p.PH); n = (int)(r / p.PH); }
+            const unsigned short* base = p.b + n * p.bs_n + c;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (t < p.ntaps && ok) {
+                    const int by = py * p.stride + p.tap_dy[t], bx = px * p.stride + p.tap_dx[t];
+                    if ((unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW)
+                        v = *reinterpret_cast<const short8_t*>(base + (int64_t)by * p.bs_h + (int64_t)bx * p.bs_w);
+                }
+                rb[t][l] = v;
+            }
+        }
+    };
+    auto write_tiles = [&]() {
+#pragma unroll
+        for (int l = 0; l < LA; l++) {
+            const int idx = tid + 256 * l, row = idx / CHA, ch = idx % CHA;
+            *reinterpret_cast<short8_t*>(sA + row * RSA + ch * 16) = ra[l];
+        }
+#pragma unroll
+        for (int l = 0; l < LB; l++) {
+            const int idx = tid + 256 * l, row = idx / CHB, ch = idx % CHB;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                if (t < p.ntaps) *reinterpret_cast<short8_t*>(sB + t * B_BYTES + row * RSB + ch * 16) = rb[t][l];
+        }
+    };
+    // fragment for 16 channels starting at column `col` of a pixel-major tile: k = {4g+q} and {16+4g+q}
+    auto read_frag = [&](const unsigned char* tile, int rs, int col) -> short8_t {
+        const unsigned char* r0 = tile + (4 * fg + fq) * rs + (col + 4 * fp) * 2;
+        short4_t lo = lds_tr_read(r0), hi = lds_tr_read(r0 + 16 * rs);
+        return short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    if (chunk_begin < chunk_end) {
+        issue_loads(chunk_begin);
+        for (int c = chunk_begin; c < chunk_end; c++) {
+            write_tiles();
+            __syncthreads();
+            if (c + 1 < chunk_end) issue_loads(c + 1);
+            short8_t fa[TA];
+#pragma unroll
+            for (int i = 0; i < TA; i++) fa[i] = read_frag(sA, RSA, wa + 16 * i);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (t < p.ntaps) {
+                    short8_t fb[TB];
+#pragma unroll
+                    for (int j = 0; j < TB; j++) fb[j] = read_frag(sB + t * B_BYTES, RSB, wb + 16 * j);
+#pragma unroll
+                    for (int i = 0; i < TA; i++)
+#pragma unroll
+                        for (int j = 0; j < TB; j++) acc[t][i][j] = Mfma<MF>::run(fa[i], fb[j], acc[t][i][j]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- store: lane holds rows ca = .. + 4*fg + e, column cb = .. + fi ------------------------------------------------
+    const bool direct = (p.nsplit == 1);
+    float* dst_base = direct ? p.out : p.ws + (int64_t)split * p.ntaps_total * p.Ca * p.Cb;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (t >= p.ntaps) continue;
+        float* slab = dst_base + (int64_t)(p.tap0 + t) * p.Ca * p.Cb;
+#pragma unroll
+        for (int i = 0; i < TA; i++)
+#pragma unroll
+            for (int j = 0; j < TB; j++) {
+                const int cb = cb0 + wb + 16 * j + fi;
+                if (cb >= p.Cb) continue;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int ca = ca0 + wa + 16 * i + 4 * fg + e;
+                    if (ca >= p.Ca) continue;
+                    float* d = slab + (int64_t)ca * p.Cb + cb;
+                    const float v = acc[t][i][j][e];
+                    *d = (direct && p.accumulate) ? *d + v : v;
+                }
+            }
+    }
+}
+
+// out[i] (+)= sum_s ws[s][i], fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* out, int64_t n, int nsplit, int accumulate)
+{
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        float s = accumulate ? out[i] : 0.f;
+        for (int k = 0; k < nsplit; k++) s += ws[(int64_t)k * n + i];
+        out[i] = s;
+    }
+}
+
+static void plan_split(WgradArgs& a, int bca, int bcb)
+{
+    a.atiles = (a.Ca + bca - 1) / bca;
+    a.btiles = (a.Cb + bcb - 1) / bcb;
+    a.nchunks = (int)((a.P + 31) / 32);
+    const int tiles = a.atiles * a.btiles;
+    int want = (1024 + tiles - 1) / tiles;               // ~4 workgroups per CU
+    int maxsplit = a.nchunks / 8; if (maxsplit < 1) maxsplit = 1;   // at least 8 chunks of work per workgroup
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    a.chunks_per_split = (a.nchunks + want - 1) / want;
+    a.nsplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+}
+
+static bool use_big_tile(int ntaps) { return ntaps == 1; }
+
+static int fill_args(const sbg_wgrad_params* q, WgradArgs& a)
+{
+    SBG_CHECK(q && q->a && q->b && q->out, "conv2d_wgrad: null pointer");
+    SBG_CHECK(q->dtype == SBG_BF16 || q->dtype == SBG_F16, "conv2d_wgrad: a/b must be bf16 or f16 (fp32 inputs are split by the host)");
+    SBG_CHECK(q->N >= 0 && q->PH >= 1 && q->PW >= 1 && q->BH >= 1 && q->BW >= 1, "conv2d_wgrad: bad sizes");
+    SBG_CHECK(q->Ca >= 8 && q->Cb >= 8 && (q->Ca % 8) == 0 && (q->Cb % 8) == 0, "conv2d_wgrad: channel counts must be multiples of 8 (pad on the host)");
+    SBG_CHECK(q->ntaps >= 1 && q->ntaps <= SBG_MAX_TAPS, "conv2d_wgrad: 1..%d taps", SBG_MAX_TAPS);
+    SBG_CHECK(q->stride >= 1, "conv2d_wgrad: stride must be >= 1");
+    SBG_CHECK(sbg_aligned16(q->a) && sbg_aligned16(q->b), "conv2d_wgrad: a and b must be 16-byte aligned");
+    SBG_CHECK((q->as_n % 8) == 0 && (q->as_h % 8) == 0 && (q->as_w % 8) == 0 && (q->bs_n % 8) == 0 && (q->bs_h % 8) == 0 && (q->bs_w % 8) == 0,
+              "conv2d_wgrad: pixel / row strides must be multiples of 8 elements");
+    a.a = (const unsigned short*)q->a; a.b = (const unsigned short*)q->b; a.out = q->out; a.ws = (float*)q->workspace;
+    a.N = q->N; a.PH = q->PH; a.PW = q->PW; a.Ca = q->Ca; a.BH = q->BH; a.BW = q->BW; a.Cb = q->Cb;
+    a.as_n = q->as_n; a.as_h = q->as_h; a.as_w = q->as_w; a.bs_n = q->bs_n; a.bs_h = q->bs_h; a.bs_w = q->bs_w;
+    a.stride = q->stride; a.ntaps = q->ntaps; a.accumulate = q->accumulate;
+    for (int t = 0; t < SBG_MAX_TAPS; t++) { a.tap_dy[t] = q->tap_dy[t]; a.tap_dx[t] = q->tap_dx[t]; }
+    a.P = (int64_t)q->N * q->PH * q->PW;
+    a.tap0 = 0; a.ntaps_total = q->ntaps;
+    if (use_big_tile(q->ntaps)) plan_split(a, 128, 128); else plan_split(a, 64, 64);
+    return SBG_OK;
+}
+
+template <class MF, int BCA, int BCB, int NT>
+static int launch_wgrad(const WgradArgs& a, hipStream_t stream)
+{
+    constexpr int lds = 32 * (BCA * 2 + 32) + NT * 32 * (BCB * 2 + 32);
+    auto kern = conv_wgrad_kernel<MF, BCA, BCB, NT>;
+    static bool attr_set = false;     // idempotent; racing threads set the same value
+    if (lds > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_wgrad: cannot raise the dynamic LDS limit to %d bytes", lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.atiles, a.btiles, a.nsplit), dim3(256), lds, stream, a);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
+
+} // namespace
+
+extern "C" int64_t sbg_conv2d_wgrad_workspace(const sbg_wgrad_params* q)
+{
+    WgradArgs a;
+    if (fill_args(q, a) != SBG_OK) return -1;
+    if (a.nsplit <= 1) return 0;
+    return (int64_t)a.nsplit * a.ntaps_total * a.Ca * a.Cb * (int64_t)sizeof(float);
+}
+
+extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
+{
+    WgradArgs a;
+    int rc = fill_args(q, a);
+    if (rc != SBG_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t out_n = (int64_t)a.ntaps_total * a.Ca * a.Cb;
+    if (a.P == 0) {
+        if (!a.accumulate) { if (hipMemsetAsync(a.out, 0, out_n * sizeof(float), s) != hipSuccess) return sbg_fail(SBG_ERR_LAUNCH, "conv2d_wgrad: memset failed"); }
+        return SBG_OK;
+    }
+    SBG_CHECK(a.nsplit == 1 || a.ws != nullptr, "conv2d_wgrad: workspace required (%d pixel splits)", a.nsplit);
+    const bool bf = (q->dtype == SBG_BF16);
+    if (use_big_tile(a.ntaps)) {
+        rc = bf ? launch_wgrad<bf16_mfma, 128, 128, 1>(a, s) : launch_wgrad<f16_mfma, 128, 128, 1>(a, s);
+        if (rc != SBG_OK) return rc;
+    } else {
+        // taps in groups of 9 accumulator sets
+        const int total = a.ntaps;
+        for (int t0 = 0; t0 < total; t0 += 9) {
+            WgradArgs g = a;
+            g.tap0 = t0; g.ntaps = (total - t0 < 9) ? total - t0 : 9;
+            for (int t = 0; t < g.ntaps; t++) { g.tap_dy[t] = a.tap_dy[t0 + t]; g.tap_dx[t] = a.tap_dx[t0 + t]; }
+            rc = bf ? launch_wgrad<bf16_mfma, 64, 64, 9>(g, s) : launch_wgrad<f16_mfma, 64, 64, 9>(g, s);
+            if (rc != SBG_OK) return rc;
+        }
+    }
+    if (a.nsplit > 1) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(sbg_stream_grid(out_n, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
+        SBG_HIP_LAUNCH_CHECK();
+    }
+    return SBG_OK;
+}

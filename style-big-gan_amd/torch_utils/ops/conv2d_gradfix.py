@@ -1,0 +1,326 @@
+"""conv2d / conv_transpose2d with arbitrarily differentiable gradients, on the MI355X matrix cores.
+
+Host-side mirror of ``stylegan2ada/torch_utils/ops/conv2d_gradfix.py``: same public names (``enabled``,
+``weight_gradients_disabled``, ``no_weight_gradients()``, ``conv2d``, ``conv_transpose2d`` -- :22-45) and the same
+autograd structure (:107-165): the data gradient of a convolution is the opposite (transposed / plain)
+convolution, the weight gradient is its own Function whose backward is again made of convolutions, so R1 and
+path-length double-backward work.  Where the reference calls cuDNN, this module launches the hand-written
+implicit-GEMM kernels ``sbg_conv2d_igemm`` / ``sbg_conv2d_wgrad`` (csrc/conv_igemm.hip, csrc/conv_wgrad.hip).
+
+Layout / precision: activations are processed channel-minor (``torch.channels_last``; other layouts are converted),
+bf16 / f16 tensors take one MFMA pass with fp32 accumulation, fp32 tensors are split into bf16 hi + lo parts and take
+three MFMA passes (hi*hi + lo*hi + hi*lo, fp32 accumulate; relative error ~1e-5 per product).
+"""
+import contextlib
+
+import torch
+
+from ... import _lib
+
+enabled = False                     # kept for API parity; the HIP path is always used on a ROCm device
+weight_gradients_disabled = False   # forcefully disable computation of gradients with respect to the weights
+
+
+@contextlib.contextmanager
+def no_weight_gradients():
+    global weight_gradients_disabled
+    old = weight_gradients_disabled
+    weight_gradients_disabled = True
+    try:
+        yield
+    finally:
+        weight_gradients_disabled = old
+
+
+def _pair(v):
+    v = tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    assert len(v) == 2 and all(isinstance(i, int) for i in v)
+    return v
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# kernel launch helpers (no autograd)
+
+def _cl(t):
+    """channel-minor (NHWC in memory) dense copy/view of a [N, C, H, W] tensor"""
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _pad_channels(t, mult=8):
+    """zero-pad dim 1 of a [N, C, H, W] tensor up to a multiple of `mult` (channel-minor result)"""
+    c = t.shape[1]
+    cp = (c + mult - 1) // mult * mult
+    if cp == c:
+        return _cl(t)
+    out = torch.zeros([t.shape[0], cp, t.shape[2], t.shape[3]], dtype=t.dtype, device=t.device).contiguous(memory_format=torch.channels_last)
+    out[:, :c] = t
+    return out
+
+
+def _split_bf16(t):
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.to(torch.float32)).to(torch.bfloat16)
+    return hi, lo
+
+
+def _operand_passes(a, b):
+    """[(a_part, b_part), ...] MFMA passes for a product of two tensors of equal dtype."""
+    if a.dtype in (torch.bfloat16, torch.float16):
+        return [(a, b)]
+    if a.dtype == torch.float32:
+        a_hi, a_lo = _split_bf16(a)
+        b_hi, b_lo = _split_bf16(b)
+        return [(a_hi, b_hi), (a_lo, b_hi), (a_hi, b_lo)]
+    raise RuntimeError(f"conv2d: unsupported dtype {a.dtype}")
+
+
+def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=None, accumulate=False):
+    """x: [N, Cin, IH, IW] channel-minor 16-bit; wp: packed [slabs, Cout, Cin]; y: [N, Cout, YH, YW] channel-minor.
+    Writes y[:, :, y_off[0] + y_step[0]*oy, y_off[1] + y_step[1]*ox] for oy < oh, ox < ow."""
+    lib = _lib.load()
+    p = _lib.ConvParams()
+    n, cin, ih, iw = x.shape
+    cout = wp.shape[1]
+    assert wp.shape[2] == cin and x.stride(1) == 1 and y.stride(1) == 1 and wp.is_contiguous() and x.dtype == wp.dtype
+    es = y.element_size()
+    p.x, p.w = x.data_ptr(), wp.data_ptr()
+    p.y = y.data_ptr() + (y_off[0] * y.stride(2) + y_off[1] * y.stride(3)) * es
+    p.oscale = oscale.data_ptr() if oscale is not None else None
+    p.xdtype, p.ydtype = _lib.dtype_code(x.dtype), _lib.dtype_code(y.dtype)
+    p.N, p.IH, p.IW, p.Cin, p.Cout, p.OH, p.OW = n, ih, iw, cin, cout, oh, ow
+    p.xs_n, p.xs_h, p.xs_w = x.stride(0), x.stride(2), x.stride(3)
+    p.ys_n, p.ys_h, p.ys_w = y.stride(0), y.stride(2) * y_step[0], y.stride(3) * y_step[1]
+    p.ws_slab, p.ws_co = wp.stride(0), wp.stride(1)
+    p.stride, p.ntaps = stride, len(taps)
+    assert 1 <= len(taps) <= _lib.SBG_MAX_TAPS
+    for i, (dy, dx, slab) in enumerate(taps):
+        p.tap_dy[i], p.tap_dx[i], p.tap_slab[i] = dy, dx, slab
+    p.accumulate = int(accumulate)
+    _lib.check(lib.sbg_conv2d_igemm(p, _lib.stream_ptr(x.device)), "sbg_conv2d_igemm")
+
+
+def _launch_groups(taps):
+    """split a tap list into launches of at most SBG_MAX_TAPS taps"""
+    m = _lib.SBG_MAX_TAPS
+    return [taps[i:i + m] for i in range(0, len(taps), m)]
+
+
+def _conv_forward(x, w, stride, padding):
+    """y[n,co,oy,ox] = sum x[n,ci,oy*s+kh-p,ox*s+kw-p] w[co,ci,kh,kw] (correlation, like F.conv2d)."""
+    n, cin, ih, iw = x.shape
+    cout, cin_w, kh, kw = w.shape
+    assert cin == cin_w and x.dtype == w.dtype
+    (sh, sw), (ph, pw) = stride, padding
+    assert sh == sw, "conv2d: only square strides are implemented"
+    oh = (ih + 2 * ph - kh) // sh + 1
+    ow = (iw + 2 * pw - kw) // sw + 1
+    assert oh >= 1 and ow >= 1
+    xp = _pad_channels(x)
+    wpk = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
+    if xp.shape[1] != cin:
+        wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
+    taps = [(i - ph, j - pw, i * kw + j) for i in range(kh) for j in range(kw)]
+    passes = _operand_passes(xp, wpk.contiguous())
+    multi = len(passes) > 1 or len(taps) > _lib.SBG_MAX_TAPS
+    y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    first = True
+    for xa, wa in passes:
+        wa = wa.contiguous()
+        for grp in _launch_groups(taps):
+            _igemm(xa, wa, y, grp, sh, oh, ow, accumulate=not first)
+            first = False
+    return y.to(x.dtype) if y.dtype != x.dtype else y
+
+
+def _conv_transpose_forward(x, w, stride, padding, output_padding):
+    """y[n,co,iy*s-p+kh, ix*s-p+kw] += x[n,ci,iy,ix] w[ci,co,kh,kw]  (F.conv_transpose2d), computed per output phase."""
+    n, cin, ih, iw = x.shape
+    cin_w, cout, kh, kw = w.shape
+    assert cin == cin_w and x.dtype == w.dtype
+    (sh, sw), (ph, pw), (oph, opw) = stride, padding, output_padding
+    assert sh == sw, "conv_transpose2d: only square strides are implemented"
+    s = sh
+    oh = (ih - 1) * s - 2 * ph + kh + oph
+    ow = (iw - 1) * s - 2 * pw + kw + opw
+    assert oh >= 1 and ow >= 1
+    xp = _pad_channels(x)
+    wpk = w.permute(2, 3, 1, 0).reshape(kh * kw, cout, cin)
+    if xp.shape[1] != cin:
+        wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
+    passes = _operand_passes(xp, wpk.contiguous())
+    # phases: output rows oy = s*o + a use taps kh == (a + p) mod s with input row o + (a + p - kh) / s
+    phases = []
+    need_zero = False
+    for a in range(s):
+        for b in range(s):
+            goh, gow = (oh - a + s - 1) // s, (ow - b + s - 1) // s
+            if goh <= 0 or gow <= 0:
+                continue
+            taps = [((a + ph - i) // s, (b + pw - j) // s, i * kw + j)
+                    for i in range(kh) if (a + ph - i) % s == 0
+                    for j in range(kw) if (b + pw - j) % s == 0]
+            if not taps:
+                need_zero = True
+                continue
+            phases.append((a, b, goh, gow, taps))
+    multi = len(passes) > 1 or any(len(t) > _lib.SBG_MAX_TAPS for *_, t in phases)
+    alloc = torch.zeros if need_zero else torch.empty
+    y = alloc([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    first = True
+    for xa, wa in passes:
+        wa = wa.contiguous()
+        for a, b, goh, gow, taps in phases:
+            for gi, grp in enumerate(_launch_groups(taps)):
+                _igemm(xa, wa, y, grp, 1, goh, gow, y_off=(a, b), y_step=(s, s), accumulate=(not first) or gi > 0)
+        first = False
+    return y.to(x.dtype) if y.dtype != x.dtype else y
+
+
+def _wgrad(a, b, stride, taps):
+    """out[t, ca, cb] = sum_{n,py,px} a[n,ca,py,px] * b[n,cb,py*s+dy_t,px*s+dx_t]   (fp32)."""
+    lib = _lib.load()
+    assert a.dtype == b.dtype and a.shape[0] == b.shape[0]
+    ca, cb = a.shape[1], b.shape[1]
+    ap, bp = _pad_channels(a), _pad_channels(b)
+    cap, cbp = ap.shape[1], bp.shape[1]
+    out = torch.empty([len(taps), cap, cbp], dtype=torch.float32, device=a.device)
+    first = True
+    for aa, bb in _operand_passes(ap, bp):
+        for g0 in range(0, len(taps), _lib.SBG_MAX_TAPS):
+            grp = taps[g0:g0 + _lib.SBG_MAX_TAPS]
+            p = _lib.WgradParams()
+            p.a, p.b, p.out = aa.data_ptr(), bb.data_ptr(), out[g0:].data_ptr()
+            p.dtype = _lib.dtype_code(aa.dtype)
+            p.N, p.PH, p.PW, p.Ca = aa.shape[0], aa.shape[2], aa.shape[3], cap
+            p.BH, p.BW, p.Cb = bb.shape[2], bb.shape[3], cbp
+            p.as_n, p.as_h, p.as_w = aa.stride(0), aa.stride(2), aa.stride(3)
+            p.bs_n, p.bs_h, p.bs_w = bb.stride(0), bb.stride(2), bb.stride(3)
+            p.stride, p.ntaps = stride, len(grp)
+            for i, (dy, dx) in enumerate(grp):
+                p.tap_dy[i], p.tap_dx[i] = dy, dx
+            p.accumulate = int(not first)
+            nbytes = lib.sbg_conv2d_wgrad_workspace(p)
+            if nbytes < 0:
+                _lib.check(1, "sbg_conv2d_wgrad_workspace")
+            ws = torch.empty([max(nbytes, 4) // 4], dtype=torch.float32, device=a.device) if nbytes > 0 else None
+            p.workspace = ws.data_ptr() if ws is not None else None
+            _lib.check(lib.sbg_conv2d_wgrad(p, _lib.stream_ptr(a.device)), "sbg_conv2d_wgrad")
+        first = False
+    return out[:, :ca, :cb]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# autograd
+
+def _output_padding_for(transpose, stride, padding, in_hw, out_hw, k_hw):
+    """output_padding of the data-gradient op (reference: conv2d_gradfix.py:95-104)."""
+    if transpose:
+        return (0, 0)
+    return tuple(in_hw[i] - (out_hw[i] - 1) * stride[i] - (1 - 2 * padding[i]) - (k_hw[i] - 1) for i in range(2))
+
+
+class _Conv(torch.autograd.Function):
+    """cfg = (transpose, stride, padding, output_padding); weight is [Cout, Cin, kh, kw] (plain) or [Cin, Cout, kh, kw] (transpose)."""
+
+    @staticmethod
+    def forward(ctx, x, w, cfg):
+        transpose, stride, padding, output_padding = cfg
+        _lib.require_cuda(x, "conv2d")
+        if x.dtype != w.dtype:
+            raise RuntimeError(f"conv2d: input ({x.dtype}) and weight ({w.dtype}) must have the same dtype")
+        if not transpose:
+            y = _conv_forward(x, w, stride, padding)
+        else:
+            y = _conv_transpose_forward(x, w, stride, padding, output_padding)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        transpose, stride, padding, output_padding = ctx.cfg
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            op = _output_padding_for(transpose, stride, padding, x.shape[2:], dy.shape[2:], w.shape[2:])
+            dx = _Conv.apply(dy, w, (not transpose, stride, padding, op))
+            assert dx.shape == x.shape
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            dw = _ConvWgrad.apply(dy, x, ctx.cfg, tuple(w.shape))
+        return dx, dw, None
+
+
+class _ConvWgrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, x, cfg, wshape):
+        transpose, stride, padding, _ = cfg
+        kh, kw = wshape[2], wshape[3]
+        taps = [(i - padding[0], j - padding[1]) for i in range(kh) for j in range(kw)]
+        assert stride[0] == stride[1]
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if not transpose:
+            out = _wgrad(dy, x, stride[0], taps)     # [t, Cout, Cin]
+        else:
+            out = _wgrad(x, dy, stride[0], taps)     # [t, Cin, Cout]
+        dw = out.reshape(kh, kw, wshape[0], wshape[1]).permute(2, 3, 0, 1).to(x.dtype)
+        ctx.save_for_backward(dy, x)
+        ctx.cfg, ctx.wshape = cfg, wshape
+        return dw
+
+    @staticmethod
+    def backward(ctx, ddw):
+        dy, x = ctx.saved_tensors
+        transpose, stride, padding, output_padding = ctx.cfg
+        d_dy = d_x = None
+        if ctx.needs_input_grad[0]:
+            d_dy = _Conv.apply(x, ddw, ctx.cfg)
+            assert d_dy.shape == dy.shape
+        if ctx.needs_input_grad[1]:
+            op = _output_padding_for(transpose, stride, padding, x.shape[2:], dy.shape[2:], ctx.wshape[2:])
+            d_x = _Conv.apply(dy, ddw, (not transpose, stride, padding, op))
+            assert d_x.shape == x.shape
+        return d_dy, d_x, None, None
+
+
+def _grouped(fn, input, weight, groups, transpose):
+    """groups > 1: one launch set per group (only the eval-time fused modulated conv and depthwise filters use it)."""
+    cin_g = input.shape[1] // groups
+    outs = []
+    wg = weight.shape[0] // groups
+    for g in range(groups):
+        outs.append(fn(input[:, g * cin_g:(g + 1) * cin_g], weight[g * wg:(g + 1) * wg]))
+    return torch.cat(outs, dim=1)
+
+
+def _add_bias(y, bias):
+    if bias is None:
+        return y
+    from . import bias_act
+    return bias_act.bias_act(y, bias.to(y.dtype))
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """Same contract as torch.nn.functional.conv2d / the reference's conv2d (conv2d_gradfix.py:35), HIP kernels inside."""
+    _lib.require_cuda(input, "conv2d")
+    assert _pair(dilation) == (1, 1), "conv2d: dilation is not implemented"
+    cfg = (False, _pair(stride), _pair(padding), (0, 0))
+    assert all(p >= 0 for p in cfg[2]) and all(s >= 1 for s in cfg[1])
+    if groups == 1:
+        y = _Conv.apply(input, weight, cfg)
+    else:
+        y = _grouped(lambda a, b: _Conv.apply(a, b, cfg), input, weight, groups, False)
+    return _add_bias(y, bias)
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    """Same contract as torch.nn.functional.conv_transpose2d / the reference's conv_transpose2d (conv2d_gradfix.py:40)."""
+    _lib.require_cuda(input, "conv_transpose2d")
+    assert _pair(dilation) == (1, 1), "conv_transpose2d: dilation is not implemented"
+    cfg = (True, _pair(stride), _pair(padding), _pair(output_padding))
+    assert all(0 <= cfg[3][i] < max(cfg[1][i], 1) or cfg[3][i] == 0 for i in range(2))
+    if groups == 1:
+        y = _Conv.apply(input, weight, cfg)
+    else:
+        y = _grouped(lambda a, b: _Conv.apply(a, b, cfg), input, weight, groups, True)
+    return _add_bias(y, bias)

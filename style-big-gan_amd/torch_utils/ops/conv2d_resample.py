@@ -1,0 +1,80 @@
+"""2-D convolution with optional FIR up / down-sampling.
+
+Host-side mirror of ``stylegan2ada/torch_utils/ops/conv2d_resample.py`` (``conv2d_resample`` :59-154): the same
+decision tree over (kernel size, up, down) and the same padding arithmetic, expressed over this package's HIP-backed
+``conv2d_gradfix`` and ``upfirdn2d``.  `flip_weight=True` means correlation (what conv2d computes), False means true
+convolution (the weight is flipped first), exactly as in the reference (:29-54).
+"""
+import torch
+
+from . import conv2d_gradfix
+from . import upfirdn2d
+from .upfirdn2d import _get_filter_size, _parse_padding
+
+
+def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
+    """plain / transposed convolution; flips the taps when a true convolution is requested"""
+    if not flip_weight:
+        w = w.flip([2, 3])
+    fn = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
+    return fn(x, w, stride=stride, padding=padding, groups=groups)
+
+
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
+    """x: [N, Cin, H, W]; w: [Cout, Cin // groups, kh, kw] (same dtype); f: filter from upfirdn2d.setup_filter().
+    `padding` is relative to the upsampled image.  Returns [N, Cout, H * up // down (+ padding), ...]."""
+    assert isinstance(x, torch.Tensor) and x.ndim == 4
+    assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
+    assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
+    assert isinstance(up, int) and up >= 1 and isinstance(down, int) and down >= 1
+    assert isinstance(groups, int) and groups >= 1
+    cout, cin_g, kh, kw = [int(s) for s in w.shape]
+    fw, fh = _get_filter_size(f)
+    px0, px1, py0, py1 = _parse_padding(padding)
+
+    # The FIR kernels eat part of the requested padding.
+    if up > 1:
+        px0 += (fw + up - 1) // 2; px1 += (fw - up) // 2
+        py0 += (fh + up - 1) // 2; py1 += (fh - up) // 2
+    if down > 1:
+        px0 += (fw - down + 1) // 2; px1 += (fw - down) // 2
+        py0 += (fh - down + 1) // 2; py1 += (fh - down) // 2
+    pad4 = [px0, px1, py0, py1]
+    pointwise = (kh == 1 and kw == 1)
+
+    if pointwise and down > 1 and up == 1:          # resample on the cheap side of a 1x1 conv: first shrink ...
+        x = upfirdn2d.upfirdn2d(x, f, down=down, padding=pad4, flip_filter=flip_filter)
+        return _conv(x, w, groups=groups, flip_weight=flip_weight)
+
+    if pointwise and up > 1 and down == 1:          # ... or convolve first, then grow
+        x = _conv(x, w, groups=groups, flip_weight=flip_weight)
+        return upfirdn2d.upfirdn2d(x, f, up=up, padding=pad4, gain=up ** 2, flip_filter=flip_filter)
+
+    if down > 1 and up == 1:                        # low-pass at full resolution, then a strided convolution
+        x = upfirdn2d.upfirdn2d(x, f, padding=pad4, flip_filter=flip_filter)
+        return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight)
+
+    if up > 1:                                      # transposed strided convolution, then low-pass (and optional decimation)
+        if groups == 1:
+            wt = w.transpose(0, 1)
+        else:
+            wt = w.reshape(groups, cout // groups, cin_g, kh, kw).transpose(1, 2).reshape(groups * cin_g, cout // groups, kh, kw)
+        px0 -= kw - 1; px1 -= kw - up
+        py0 -= kh - 1; py1 -= kh - up
+        pxt = max(min(-px0, -px1), 0)
+        pyt = max(min(-py0, -py1), 0)
+        x = _conv(x, wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
+        x = upfirdn2d.upfirdn2d(x, f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2, flip_filter=flip_filter)
+        if down > 1:
+            x = upfirdn2d.upfirdn2d(x, f, down=down, flip_filter=flip_filter)
+        return x
+
+    if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:     # plain convolution with symmetric padding
+        return _conv(x, w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
+
+    # generic composition: pad/crop with an identity FIR, convolve, decimate
+    x = upfirdn2d.upfirdn2d(x, (f if up > 1 else None), up=up, padding=pad4, gain=up ** 2, flip_filter=flip_filter)
+    x = _conv(x, w, groups=groups, flip_weight=flip_weight)
+    if down > 1:
+        x = upfirdn2d.upfirdn2d(x, f, down=down, flip_filter=flip_filter)
+    return x

@@ -1,0 +1,178 @@
+"""FIR resampling (pad -> zero-insert upsample -> filter -> decimate) on MI355X.
+
+Host-side mirror of ``stylegan2ada/torch_utils/ops/upfirdn2d.py`` (``setup_filter`` :72, ``upfirdn2d`` :120,
+``filter2d`` :272, ``upsample2d`` :308, ``downsample2d`` :347): same names, arguments, padding arithmetic and
+gradient definition (:214-268 -- the gradient of an upfirdn is the upfirdn with up/down swapped, the filter
+flipped and the complementary padding, hence gradients of any order).  The arithmetic runs in ``sbg_upfirdn2d``
+(csrc/upfirdn2d.hip) for both memory layouts.
+"""
+import numpy as np
+import torch
+
+from ... import _lib
+
+
+def _pair(v):
+    """int or [x, y] -> (x, y)"""
+    if isinstance(v, int):
+        v = [v, v]
+    assert isinstance(v, (list, tuple)) and len(v) == 2 and all(isinstance(i, int) for i in v)
+    sx, sy = v
+    assert sx >= 1 and sy >= 1
+    return sx, sy
+
+
+def _parse_scaling(scaling):
+    return _pair(scaling)
+
+
+def _parse_padding(padding):
+    """int | [x, y] | [x0, x1, y0, y1] -> (x0, x1, y0, y1)"""
+    if isinstance(padding, int):
+        padding = [padding, padding]
+    assert isinstance(padding, (list, tuple)) and all(isinstance(i, (int, np.integer)) for i in padding)
+    padding = [int(i) for i in padding]
+    if len(padding) == 2:
+        px, py = padding
+        padding = [px, px, py, py]
+    x0, x1, y0, y1 = padding
+    return x0, x1, y0, y1
+
+
+def _get_filter_size(f):
+    """-> (fw, fh); None is the 1x1 identity."""
+    if f is None:
+        return 1, 1
+    assert isinstance(f, torch.Tensor) and f.ndim in [1, 2]
+    fw, fh = int(f.shape[-1]), int(f.shape[0])
+    assert fw >= 1 and fh >= 1
+    return fw, fh
+
+
+def setup_filter(f, device=torch.device("cpu"), normalize=True, flip_filter=False, gain=1, separable=None):
+    """Prepare a float32 FIR filter: [fh, fw] (non-separable) or [taps] (separable; chosen automatically for
+    1-D inputs with >= 8 taps).  None -> identity.  Same contract as the reference's ``setup_filter`` (:72-116)."""
+    f = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
+    assert f.ndim in [0, 1, 2] and f.numel() > 0
+    if f.ndim == 0:
+        f = f.reshape(1)
+    if separable is None:
+        separable = f.ndim == 1 and f.numel() >= 8
+    if f.ndim == 1 and not separable:
+        f = torch.outer(f, f)
+    assert f.ndim == (1 if separable else 2)
+    if normalize:
+        f = f / f.sum()
+    if flip_filter:
+        f = f.flip(list(range(f.ndim)))
+    f = f * (gain ** (f.ndim / 2))
+    return f.to(device=device)
+
+
+def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
+    """One sbg_upfirdn2d launch on a rank-2 filter; output keeps x's memory format (reference: upfirdn2d.cpp:35)."""
+    lib = _lib.load()
+    if x.ndim != 4:
+        raise RuntimeError("upfirdn2d: x must be rank 4")
+    if f2d.dtype != torch.float32 or f2d.ndim != 2 or f2d.device != x.device:
+        raise RuntimeError("upfirdn2d: f must be a float32 rank-2 tensor on the same device as x")
+    n, c, ih, iw = x.shape
+    fh, fw = f2d.shape
+    ow = (iw * upx + padx0 + padx1 - fw + downx) // downx
+    oh = (ih * upy + pady0 + pady1 - fh + downy) // downy
+    if ow < 1 or oh < 1:
+        raise RuntimeError("upfirdn2d: output must be at least 1x1")
+    cl = x.stride(1) == 1 and c > 1
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device,
+                    memory_format=torch.channels_last if cl else torch.contiguous_format)
+    p = _lib.UpfirdnParams()
+    p.x, p.f, p.y = x.data_ptr(), f2d.data_ptr(), y.data_ptr()
+    p.dtype = _lib.dtype_code(x.dtype)
+    p.upx, p.upy, p.downx, p.downy, p.padx0, p.pady0 = upx, upy, downx, downy, padx0, pady0
+    p.flip, p.gain = int(bool(flip)), float(gain)
+    p.inSize[:] = [iw, ih, c, n]
+    p.inStride[:] = [x.stride(3), x.stride(2), x.stride(1), x.stride(0)]
+    p.filterSize[:] = [fw, fh]
+    p.filterStride[:] = [f2d.stride(1), f2d.stride(0)]
+    p.outSize[:] = [ow, oh, c, n]
+    p.outStride[:] = [y.stride(3), y.stride(2), y.stride(1), y.stride(0)]
+    _lib.check(lib.sbg_upfirdn2d(p, _lib.stream_ptr(x.device)), "sbg_upfirdn2d")
+    return y
+
+
+class _Upfirdn2d(torch.autograd.Function):
+    """cfg = (upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)"""
+
+    @staticmethod
+    def forward(ctx, x, f, cfg):
+        upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain = cfg
+        if f is None:
+            f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+        assert f.ndim in [1, 2]
+        if f.ndim == 2:
+            y = _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+        else:   # separable: a row pass then a column pass, sqrt(gain) each
+            g = float(np.sqrt(gain))
+            y = _launch(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip, g)
+            y = _launch(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip, g)
+        ctx.save_for_backward(f)
+        ctx.cfg, ctx.in_hw = cfg, (x.shape[2], x.shape[3])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (f,) = ctx.saved_tensors
+        upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain = ctx.cfg
+        dx = None
+        if ctx.needs_input_grad[0]:
+            ih, iw = ctx.in_hw
+            oh, ow = dy.shape[2], dy.shape[3]
+            fw, fh = _get_filter_size(f)
+            gcfg = (downx, downy, upx, upy,
+                    fw - padx0 - 1, iw * upx - ow * downx + padx0 - upx + 1,
+                    fh - pady0 - 1, ih * upy - oh * downy + pady0 - upy + 1,
+                    not flip, gain)
+            dx = _Upfirdn2d.apply(dy, f, gcfg)
+        return dx, None, None
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="cuda"):
+    """Pad, upsample, filter and downsample a batch of 2-D images [N, C, H, W] (reference: upfirdn2d.py:120).
+    padding is w.r.t. the upsampled image, negative = crop; flip_filter False = convolution, True = correlation."""
+    assert isinstance(x, torch.Tensor)
+    assert impl in ["ref", "cuda"]
+    if impl == "ref":
+        raise RuntimeError("upfirdn2d: impl='ref' is not part of the MI355X build (the CPU restatement is oracle/, test-only)")
+    _lib.require_cuda(x, "upfirdn2d")
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    assert f is None or (isinstance(f, torch.Tensor) and f.dtype == torch.float32 and not f.requires_grad)
+    cfg = (upx, upy, downx, downy, padx0, padx1, pady0, pady1, bool(flip_filter), float(gain))
+    return _Upfirdn2d.apply(x, f, cfg)
+
+
+def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl="cuda"):
+    """FIR-filter keeping the input size (extra `padding` on top).  Reference: upfirdn2d.py:272-304."""
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [px0 + fw // 2, px1 + (fw - 1) // 2, py0 + fh // 2, py1 + (fh - 1) // 2]
+    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl="cuda"):
+    """Upsample by `up`; output size = up * input size (+ padding).  Reference: upfirdn2d.py:308-343."""
+    upx, upy = _parse_scaling(up)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [px0 + (fw + upx - 1) // 2, px1 + (fw - upx) // 2, py0 + (fh + upy - 1) // 2, py1 + (fh - upy) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl)
+
+
+def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl="cuda"):
+    """Downsample by `down`; output size = input size / down (+ padding).  Reference: upfirdn2d.py:347-382."""
+    downx, downy = _parse_scaling(down)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [px0 + (fw - downx + 1) // 2, px1 + (fw - downx) // 2, py0 + (fh - downy + 1) // 2, py1 + (fh - downy) // 2]
+    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)

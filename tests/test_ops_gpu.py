@@ -1,0 +1,230 @@
+"""GPU parity: HIP ops (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per dtype): fp32 tensors -- elementwise ops 1e-5 abs/rel, MFMA convolutions (bf16x3 split) 2e-4
+relative to the output's max magnitude; bf16 / f16 tensors -- 2e-2 relative to the output's max magnitude
+(8-bit / 11-bit mantissa storage, fp32 accumulation).
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+import style_big_gan_amd  # noqa: F401
+from style_big_gan_amd.torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, fma, upfirdn2d
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def check(a, b, tol, what=""):
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    e = rel_err(a, b)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+TOL = {torch.float32: 1e-5, torch.bfloat16: 2e-2, torch.float16: 4e-3}
+CONV_TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2, torch.float16: 4e-3}
+
+
+# ---------------------------------------------------------------------------------------------------- bias_act
+
+@pytest.mark.parametrize("act", list(bias_act.activation_funcs.keys()))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_act_forward_and_grads(dev, act, dtype):
+    torch.manual_seed(1)
+    for shape, dim, cl in [((2, 5, 4, 4), 1, False), ((3, 16, 6, 5), 1, True), ((3, 7), 1, False), ((4, 8, 3, 3), 1, False)]:
+        for clamp, gain in [(None, None), (0.5, 2.0)]:
+            x0 = torch.randn(shape)
+            b0 = torch.randn(shape[dim])
+            xq, bq = x0.to(dtype).float(), b0.to(dtype).float()      # same quantised inputs on both sides
+            xr = xq.clone().requires_grad_(True); br = bq.clone().requires_grad_(True)
+            yr = O.bias_act(xr, br, dim=dim, act=act, gain=gain, clamp=clamp)
+            xg = xq.to(dev, dtype)
+            if cl:
+                xg = xg.contiguous(memory_format=torch.channels_last)
+            xg.requires_grad_(True)
+            bg = bq.to(dev, dtype).requires_grad_(True)
+            yg = bias_act.bias_act(xg, bg, dim=dim, act=act, gain=gain, clamp=clamp)
+            check(yg, yr, TOL[dtype], f"{act} y")
+            dy = torch.randn(shape).to(dtype).float()
+            gxr, gbr = torch.autograd.grad((yr * dy).sum(), [xr, br], create_graph=True)
+            gxg, gbg = torch.autograd.grad((yg * dy.to(dev, dtype)).sum(), [xg, bg], create_graph=True)
+            check(gxg, gxr, TOL[dtype] * 2, f"{act} dx")
+            check(gbg, gbr, TOL[dtype] * 4, f"{act} db")
+            if dtype == torch.float32:      # second order (R1-style): d/dx of |dx|^2
+                ggr = torch.autograd.grad(gxr.square().sum(), [xr], allow_unused=True)[0]
+                ggg = torch.autograd.grad(gxg.square().sum(), [xg], allow_unused=True)[0]
+                if ggr is None or float(ggr.abs().max()) == 0:
+                    assert ggg is None or float(ggg.abs().max()) < 1e-6
+                else:
+                    check(ggg, ggr, 1e-4, f"{act} d2x")
+
+
+def test_bias_act_no_bias_and_unaligned(dev):
+    torch.manual_seed(2)
+    x = torch.randn(3, 5, 7)
+    y = bias_act.bias_act(x.to(dev), act="lrelu")
+    check(y, O.bias_act(x, act="lrelu"), 1e-6)
+    base = torch.randn(1001, device=dev)
+    xs = base[1:]                       # 4-byte aligned only
+    y = bias_act.bias_act(xs, act="swish", clamp=0.7)
+    check(y, O.bias_act(xs.cpu(), act="swish", clamp=0.7), 1e-5)
+    with pytest.raises(RuntimeError):
+        bias_act.bias_act(torch.randn(4, 4), act="relu")      # CPU tensors are refused: no CPU path in the product
+
+
+# ---------------------------------------------------------------------------------------------------- upfirdn2d
+
+FILTERS = {
+    "k4": [1, 3, 3, 1],
+    "sym6": [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466,
+             0.787641141030194, 0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578,
+             0.0017677118642428036, -0.007800708325034148],
+    "none": None,
+    "k3x2": [[1., 2., 1.], [0.5, -1., 3.]],
+}
+
+
+@pytest.mark.parametrize("fname", list(FILTERS.keys()))
+@pytest.mark.parametrize("updown", [(1, 1), (2, 1), (1, 2), (2, 2), (3, 2)])
+def test_upfirdn2d(dev, fname, updown):
+    torch.manual_seed(3)
+    up, down = updown
+    f = None if FILTERS[fname] is None else O.setup_filter(FILTERS[fname], normalize=(fname != "k3x2"))
+    for shape, cl, dtype in [((2, 3, 8, 8), False, torch.float32), ((1, 4, 9, 9), False, torch.float32),
+                             ((2, 16, 9, 7), True, torch.float32), ((2, 8, 10, 12), True, torch.bfloat16)]:
+        for padding, flip, gain in [(0, False, 1), ([2, 1, 2, 1], True, 4), ([-1, 2, 3, -1], False, 1)]:
+            fw, fh = O._fsize(f)
+            px0, px1, py0, py1 = O._pad4(padding)
+            if (shape[3] * up + px0 + px1 - fw) < 0 or (shape[2] * up + py0 + py1 - fh) < 0:
+                continue
+            xq = torch.randn(shape).to(dtype).float()
+            xr = xq.clone().requires_grad_(True)
+            yr = O.upfirdn2d(xr, f, up=up, down=down, padding=padding, flip_filter=flip, gain=gain)
+            xg = xq.to(dev, dtype)
+            if cl:
+                xg = xg.contiguous(memory_format=torch.channels_last)
+            xg.requires_grad_(True)
+            fg = f.to(dev) if f is not None else None
+            yg = upfirdn2d.upfirdn2d(xg, fg, up=up, down=down, padding=padding, flip_filter=flip, gain=gain)
+            check(yg, yr, TOL[dtype], f"upfirdn {fname} {updown} {padding}")
+            dy = torch.randn(yr.shape).to(dtype).float()
+            gr = torch.autograd.grad((yr * dy).sum(), xr)[0]
+            gg = torch.autograd.grad((yg * dy.to(dev, dtype)).sum(), xg, create_graph=True)[0]
+            check(gg, gr, TOL[dtype] * 2, f"upfirdn grad {fname} {updown} {padding}")
+            if dtype == torch.float32 and not cl:   # grad of grad is linear in dy: check it runs and matches forward
+                g2 = torch.autograd.grad((gg * xq.to(dev)).sum(), xg, allow_unused=True)[0]
+                assert g2 is None or torch.isfinite(g2).all()
+
+
+def test_upfirdn2d_wrappers(dev):
+    torch.manual_seed(4)
+    f = O.setup_filter([1, 3, 3, 1])
+    x = torch.randn(2, 3, 16, 16)
+    for name in ["filter2d", "upsample2d", "downsample2d"]:
+        yr = getattr(O, name)(x, f)
+        yg = getattr(upfirdn2d, name)(x.to(dev), f.to(dev))
+        check(yg, yr, 1e-5, name)
+    assert torch.equal(upfirdn2d.setup_filter([1, 3, 3, 1]), f)
+    assert upfirdn2d.setup_filter(FILTERS["sym6"]).ndim == 1
+
+
+# ---------------------------------------------------------------------------------------------------- conv
+
+def _conv_case(dev, dtype, n, cin, cout, h, w, k, stride, pad, transpose, second_order=False):
+    torch.manual_seed(5)
+    xq = torch.randn(n, cin, h, w).to(dtype).float()
+    wshape = (cin, cout, k, k) if transpose else (cout, cin, k, k)
+    wq = (torch.randn(wshape) / np.sqrt(cin * k * k)).to(dtype).float()
+    xr = xq.clone().requires_grad_(True); wr = wq.clone().requires_grad_(True)
+    if transpose:
+        yr = torch.nn.functional.conv_transpose2d(xr, wr, stride=stride, padding=pad)
+    else:
+        yr = torch.nn.functional.conv2d(xr, wr, stride=stride, padding=pad)
+    xg = xq.to(dev, dtype).requires_grad_(True); wg = wq.to(dev, dtype).requires_grad_(True)
+    fn = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
+    yg = fn(xg, wg, stride=stride, padding=pad)
+    tol = CONV_TOL[dtype]
+    tag = f"conv n{n} {cin}->{cout} {h}x{w} k{k} s{stride} p{pad} T{int(transpose)} {dtype}"
+    check(yg, yr, tol, tag + " y")
+    dy = torch.randn(yr.shape).to(dtype).float()
+    gxr, gwr = torch.autograd.grad((yr * dy).sum(), [xr, wr], create_graph=second_order)
+    gxg, gwg = torch.autograd.grad((yg * dy.to(dev, dtype)).sum(), [xg, wg], create_graph=second_order)
+    check(gxg, gxr, tol, tag + " dx")
+    check(gwg, gwr, tol * 2, tag + " dw")
+    if second_order:    # R1-style: gradient of |dx|^2 w.r.t. weights and of |dw|^2 w.r.t. x
+        r2 = torch.autograd.grad(gxr.square().sum() + gwr.square().sum(), [xr, wr])
+        g2 = torch.autograd.grad(gxg.square().sum() + gwg.square().sum(), [xg, wg])
+        check(g2[0], r2[0], tol * 4, tag + " d2x")
+        check(g2[1], r2[1], tol * 4, tag + " d2w")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_conv2d_shapes(dev, dtype):
+    cases = [
+        # n, cin, cout, h, w, k, stride, pad, transpose
+        (2, 16, 32, 8, 8, 3, 1, 1, False),
+        (1, 8, 8, 5, 7, 3, 1, 1, False),
+        (3, 3, 24, 9, 9, 1, 1, 0, False),        # fromrgb-like: Cin = 3 (padded to 8 on the host)
+        (2, 40, 3, 8, 8, 1, 1, 0, False),        # torgb-like: Cout = 3
+        (2, 24, 16, 9, 9, 3, 2, 0, False),       # stride-2 (D down path)
+        (2, 16, 24, 4, 4, 3, 2, 0, True),        # transposed stride-2 (G up path), out 9x9
+        (2, 136, 200, 6, 6, 3, 1, 1, False),     # ragged channels (Cin % 32 != 0, Cout % 128 != 0)
+        (1, 520, 72, 4, 4, 3, 1, 1, False),
+        (2, 16, 16, 6, 6, 3, 1, 0, True),        # transposed stride-1
+        (2, 16, 16, 7, 5, 3, 2, 1, False),
+        (2, 16, 8, 5, 5, 4, 2, 1, True),         # 4x4 transposed (DCGAN-style)
+    ]
+    for c in cases:
+        _conv_case(dev, dtype, *c)
+
+
+def test_conv2d_double_backward(dev):
+    _conv_case(dev, torch.float32, 2, 16, 24, 6, 6, 3, 1, 1, False, second_order=True)
+    _conv_case(dev, torch.float32, 2, 16, 8, 9, 9, 3, 2, 0, False, second_order=True)
+    _conv_case(dev, torch.float32, 2, 8, 16, 4, 4, 3, 2, 0, True, second_order=True)
+
+
+def test_conv2d_large_k_and_many_pixels(dev):
+    # enough pixels that the weight-gradient kernel splits the pixel axis across workgroups
+    _conv_case(dev, torch.bfloat16, 4, 64, 64, 64, 64, 3, 1, 1, False)
+    _conv_case(dev, torch.float32, 2, 32, 32, 40, 40, 3, 1, 1, False)
+    _conv_case(dev, torch.bfloat16, 2, 128, 128, 32, 32, 1, 1, 0, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv2d_resample(dev, dtype):
+    torch.manual_seed(6)
+    f = O.setup_filter([1, 3, 3, 1])
+    for k, (up, down), flip_weight, groups in itertools.product([1, 3], [(1, 1), (2, 1), (1, 2)], [True, False], [1, 2]):
+        xq = torch.randn(2, 16, 8, 8).to(dtype).float()
+        wq = (torch.randn(24, 16 // groups, k, k) / np.sqrt(16 * k * k / groups)).to(dtype).float()
+        xr = xq.clone().requires_grad_(True); wr = wq.clone().requires_grad_(True)
+        yr = O.conv2d_resample(xr, wr, f=f, up=up, down=down, padding=k // 2, groups=groups, flip_weight=flip_weight)
+        xg = xq.to(dev, dtype).requires_grad_(True); wg = wq.to(dev, dtype).requires_grad_(True)
+        yg = conv2d_resample.conv2d_resample(xg, wg, f=f.to(dev), up=up, down=down, padding=k // 2, groups=groups, flip_weight=flip_weight)
+        tag = f"resample k{k} up{up} down{down} flip{flip_weight} g{groups} {dtype}"
+        check(yg, yr, CONV_TOL[dtype] * 2, tag)
+        dy = torch.randn(yr.shape).to(dtype).float()
+        gr = torch.autograd.grad((yr * dy).sum(), [xr, wr])
+        gg = torch.autograd.grad((yg * dy.to(dev, dtype)).sum(), [xg, wg])
+        check(gg[0], gr[0], CONV_TOL[dtype] * 2, tag + " dx")
+        check(gg[1], gr[1], CONV_TOL[dtype] * 4, tag + " dw")
+
+
+def test_fma(dev):
+    torch.manual_seed(7)
+    a = torch.randn(2, 4, 5, 5, requires_grad=True); b = torch.randn(2, 4, 1, 1, requires_grad=True); c = torch.randn(2, 1, 5, 5, requires_grad=True)
+    ag, bg, cg = [t.detach().to(dev).requires_grad_(True) for t in (a, b, c)]
+    yr = O.fma(a, b, c); yg = fma.fma(ag, bg, cg)
+    check(yg, yr, 1e-6)
+    gr = torch.autograd.grad(yr.square().sum(), [a, b, c]); gg = torch.autograd.grad(yg.square().sum(), [ag, bg, cg])
+    for u, v in zip(gg, gr):
+        check(u, v, 1e-5)
