@@ -47,6 +47,13 @@ class _Cfg(tuple):
     def trivial(self):
         return self.act == "linear" and self.gain == 1 and self.clamp < 0
 
+    @property
+    def needs_y(self):
+        # The gradient's clamp mask is evaluated on the forward output.  The reference's CUDA plugin does not keep `y` for
+        # 'linear' (ref=''), which makes its gradient ignore the clamp there; the reference's eager CPU path (the parity
+        # target) zeroes the gradient of clamped elements for every activation, so `y` is kept for linear + clamp too.
+        return "y" in self.spec.ref or (self.act == "linear" and self.clamp >= 0)
+
 
 def _dense_like_format(x):
     """The memory format the kernel runs in: channels_last when x is 4-D channel-minor, else contiguous."""
@@ -92,7 +99,7 @@ class _BiasAct(torch.autograd.Function):
         y = x if (cfg.trivial and b is None) else _run(x, b, None, None, None, 0, cfg, fmt)
         spec = cfg.spec
         keep_x = ("x" in spec.ref) or spec.has_2nd_grad
-        ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if "y" in spec.ref else None)
+        ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if cfg.needs_y else None)
         ctx.cfg, ctx.fmt = cfg, fmt
         return y
 
