@@ -128,6 +128,23 @@ typedef struct sbg_wgrad_params {
 int64_t sbg_conv2d_wgrad_workspace(const sbg_wgrad_params* p);
 int     sbg_conv2d_wgrad(const sbg_wgrad_params* p, sbg_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Per-sample channel scaling with optional per-pixel addend (the modulation `x * styles`, the demodulation
+ * + noise `fma(x, dcoefs, noise)` of train_parts/generators.py:79-88 and stylegan2ada/torch_utils/ops/fma.py:15):
+ *   y[n,c,p] = x[n,c,p] * a[n*C + c] (+ z[n*z_stride_n + p])         a, z: fp32; p = pixel index in [0, HW)
+ * layout: 0 = planar [N][C][HW], 1 = channel-minor [N][HW][C]; x and y dense in that layout. */
+int sbg_scale_nc(const void* x, const float* a, const float* z, void* y, int dtype, int layout,
+                 int N, int C, int64_t HW, int64_t z_stride_n, sbg_stream_t stream);
+
+/* Per-sample, per-channel dot product over pixels (the gradient of the scaling above w.r.t. `a`, and -- with
+ * v == NULL -- the bias gradient `dx.sum([2, 3])` of bias_act.py:172-173):
+ *   partial[s][n*C + c] = sum_{p in split s} u[n,c,p] * (v ? v[n,c,p] : 1)        partial: fp32 [nsplit][N][C]
+ * The caller sums `partial` over s (fixed order => reproducible).  sbg_dot_hw_splits() returns nsplit. */
+int sbg_dot_hw_splits(int layout, int N, int C, int64_t HW);
+int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layout,
+               int N, int C, int64_t HW, sbg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

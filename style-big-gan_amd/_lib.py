@@ -80,6 +80,9 @@ SYMBOLS = [
     ("sbg_conv2d_igemm", _c.c_int, [_c.POINTER(ConvParams), _c.c_void_p]),
     ("sbg_conv2d_wgrad_workspace", _c.c_int64, [_c.POINTER(WgradParams)]),
     ("sbg_conv2d_wgrad", _c.c_int, [_c.POINTER(WgradParams), _c.c_void_p]),
+    ("sbg_scale_nc", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_void_p]),
+    ("sbg_dot_hw_splits", _c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64]),
+    ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
 ]
 
 

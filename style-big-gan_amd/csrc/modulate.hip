@@ -1,0 +1,219 @@
+// modulate.hip -- per-sample channel scaling (+ per-pixel addend) and its reduction gradient.
+//
+//   scale_nc : y[n,c,p] = x[n,c,p] * a[n,c] (+ z[n,p])      -- `x * styles` and `fma(x, dcoefs, noise)` of the modulated
+//                                                              convolution (train_parts/generators.py:79-88, ops/fma.py:15)
+//   dot_hw   : r[n,c]   = sum_p u[n,c,p] * v[n,c,p]         -- gradient w.r.t. a; with v == NULL the per-sample bias
+//                                                              gradient of bias_act (ops/bias_act.py:172-173)
+// Both are HBM-bound streaming ops: 16-B-per-lane accesses, grid sized to the chip, fp32 math.
+// dot_hw reduces in two deterministic stages (per-workgroup partial rows, then the caller's fixed-order sum).
+#include "sbg_common.h"
+
+namespace {
+
+struct ScaleArgs { const void* x; const float* a; const float* z; void* y; int N, C; int64_t HW, zsn, total; };
+
+// channel-minor: one lane = 8 channels of one pixel.
+template <class T>
+__global__ __launch_bounds__(256) void scale_nc_cminor8(ScaleArgs p)
+{
+    const T* px = (const T*)p.x; T* py = (T*)p.y;
+    const int cv = p.C >> 3;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.total; i += step) {
+        const int c = (int)(i % cv) << 3; const int64_t r = i / cv; const int64_t pix = r % p.HW; const int n = (int)(r / p.HW);
+        float v[8], a[8];
+        Vec8<T>::ld(px + (i << 3), v);
+        Vec8<float>::ld(p.a + (int64_t)n * p.C + c, a);
+        const float z = p.z ? p.z[n * p.zsn + pix] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = v[j] * a[j] + z;
+        Vec8<T>::st(py + (i << 3), v);
+    }
+}
+
+// generic scalar form for either layout.
+template <class T>
+__global__ __launch_bounds__(256) void scale_nc_scalar(ScaleArgs p, int layout)
+{
+    const T* px = (const T*)p.x; T* py = (T*)p.y;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.total; i += step) {
+        int c, n; int64_t pix;
+        if (layout == 1) { c = (int)(i % p.C); const int64_t r = i / p.C; pix = r % p.HW; n = (int)(r / p.HW); }
+        else             { pix = i % p.HW; const int64_t r = i / p.HW; c = (int)(r % p.C); n = (int)(r / p.C); }
+        const float z = p.z ? p.z[n * p.zsn + pix] : 0.f;
+        Elem<T>::st(py + i, Elem<T>::ld(px + i) * p.a[(int64_t)n * p.C + c] + z);
+    }
+}
+
+// ---- dot_hw ---------------------------------------------------------------------------------------------------------
+struct DotArgs { const void* u; const void* v; float* partial; int N, C; int64_t HW; int nsplit; int64_t pix_per_split; };
+
+#define DOT_PIX_PER_SPLIT 2048
+
+// channel-minor, C % 8 == 0: workgroup = (sample n, pixel split s); lane = (channel vector, pixel lane).
+template <class T>
+__global__ __launch_bounds__(256) void dot_hw_cminor8(DotArgs p)
+{
+    __shared__ float red[256 * 8];
+    const T* pu = (const T*)p.u; const T* pv = (const T*)p.v;
+    const int n = blockIdx.x, s = blockIdx.y;
+    const int cv = p.C >> 3;
+    const int64_t p0 = (int64_t)s * p.pix_per_split;
+    int64_t p1 = p0 + p.pix_per_split; if (p1 > p.HW) p1 = p.HW;
+    const int64_t base = (int64_t)n * p.HW * p.C;
+    // lanes own a fixed channel vector when 256 % cv == 0 (cv a power of two <= 256): 16-B coalesced loads, pixel lanes
+    // stride the split; other channel counts walk whole channel vectors serially.
+    if (cv <= 256 && (256 % cv) == 0) {
+        const int myc = threadIdx.x % cv, plane = threadIdx.x / cv, planes = 256 / cv;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0.f;
+        for (int64_t pix = p0 + plane; pix < p1; pix += planes) {
+            float a[8], b[8];
+            const int64_t off = base + pix * p.C + (myc << 3);
+            Vec8<T>::ld(pu + off, a);
+            if (pv) { Vec8<T>::ld(pv + off, b);
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] += a[j] * b[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] += a[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[threadIdx.x * 8 + j] = acc[j];
+        __syncthreads();
+        // fixed-order tree over the pixel lanes
+        for (int stride = planes >> 1; stride >= 1; stride >>= 1) {
+            if (plane < stride) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) red[threadIdx.x * 8 + j] += red[(threadIdx.x + stride * cv) * 8 + j];
+            }
+            __syncthreads();
+        }
+        if (plane == 0) {
+            float* dst = p.partial + ((int64_t)s * p.N + n) * p.C + (myc << 3);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dst[j] = red[threadIdx.x * 8 + j];
+        }
+    } else {
+        // many / odd channel vectors: each lane walks whole channel vectors serially over the split's pixels
+        for (int myc = threadIdx.x; myc < cv; myc += 256) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = 0.f;
+            for (int64_t pix = p0; pix < p1; pix++) {
+                float a[8], b[8];
+                const int64_t off = base + pix * p.C + (myc << 3);
+                Vec8<T>::ld(pu + off, a);
+                if (pv) { Vec8<T>::ld(pv + off, b);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] += a[j] * b[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] += a[j];
+                }
+            }
+            float* dst = p.partial + ((int64_t)s * p.N + n) * p.C + (myc << 3);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dst[j] = acc[j];
+        }
+    }
+}
+
+// generic: workgroup = (n, c) pair-range; one wave-reduction per (n, c); handles both layouts element-wise.
+template <class T>
+__global__ __launch_bounds__(256) void dot_hw_generic(DotArgs p, int layout)
+{
+    __shared__ float red[256];
+    const T* pu = (const T*)p.u; const T* pv = (const T*)p.v;
+    const int64_t nc = blockIdx.x;                    // n*C + c
+    const int n = (int)(nc / p.C), c = (int)(nc % p.C);
+    float acc = 0.f;
+    for (int64_t pix = threadIdx.x; pix < p.HW; pix += 256) {
+        const int64_t off = (layout == 1) ? ((int64_t)n * p.HW + pix) * p.C + c : ((int64_t)n * p.C + c) * p.HW + pix;
+        const float a = Elem<T>::ld(pu + off);
+        acc += pv ? a * Elem<T>::ld(pv + off) : a;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if ((int)threadIdx.x < stride) red[threadIdx.x] += red[threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.partial[nc] = red[0];
+}
+
+static bool dot_fast(int layout, int C) { return layout == 1 && (C % 8) == 0; }
+
+template <class T>
+static int run_scale(const ScaleArgs& a0, int layout, bool vec, hipStream_t s)
+{
+    ScaleArgs a = a0;
+    if (vec) {
+        a.total = (int64_t)a.N * a.HW * (a.C >> 3);
+        hipLaunchKernelGGL((scale_nc_cminor8<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, s, a);
+    } else {
+        a.total = (int64_t)a.N * a.HW * a.C;
+        hipLaunchKernelGGL((scale_nc_scalar<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, s, a, layout);
+    }
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
+
+template <class T>
+static int run_dot(const DotArgs& a, int layout, bool fast, hipStream_t s)
+{
+    if (fast) hipLaunchKernelGGL((dot_hw_cminor8<T>), dim3(a.N, a.nsplit), dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL((dot_hw_generic<T>), dim3((unsigned)((int64_t)a.N * a.C)), dim3(256), 0, s, a, layout);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
+
+} // namespace
+
+extern "C" int sbg_scale_nc(const void* x, const float* a, const float* z, void* y, int dtype, int layout,
+                            int N, int C, int64_t HW, int64_t z_stride_n, sbg_stream_t stream)
+{
+    SBG_CHECK(x && a && y, "scale_nc: null pointer");
+    SBG_CHECK(dtype == SBG_F32 || dtype == SBG_F16 || dtype == SBG_BF16, "scale_nc: unsupported dtype %d", dtype);
+    SBG_CHECK(layout == 0 || layout == 1, "scale_nc: layout must be 0 (planar) or 1 (channel-minor)");
+    SBG_CHECK(N >= 0 && C >= 1 && HW >= 0, "scale_nc: bad sizes");
+    if ((int64_t)N * C * HW == 0) return SBG_OK;
+    ScaleArgs p; p.x = x; p.a = a; p.z = z; p.y = y; p.N = N; p.C = C; p.HW = HW; p.zsn = z_stride_n; p.total = 0;
+    const bool vec = layout == 1 && (C % 8) == 0 && sbg_aligned16(x) && sbg_aligned16(y) && sbg_aligned16(a);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SBG_F32) return run_scale<float>(p, layout, vec, s);
+    if (dtype == SBG_F16) return run_scale<f16_s>(p, layout, vec, s);
+    return run_scale<bf16_s>(p, layout, vec, s);
+}
+
+extern "C" int sbg_dot_hw_splits(int layout, int N, int C, int64_t HW)
+{
+    if (!dot_fast(layout, C)) return 1;
+    int64_t s = (HW + DOT_PIX_PER_SPLIT - 1) / DOT_PIX_PER_SPLIT;
+    return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layout,
+                          int N, int C, int64_t HW, sbg_stream_t stream)
+{
+    SBG_CHECK(u && partial, "dot_hw: null pointer");
+    SBG_CHECK(dtype == SBG_F32 || dtype == SBG_F16 || dtype == SBG_BF16, "dot_hw: unsupported dtype %d", dtype);
+    SBG_CHECK(layout == 0 || layout == 1, "dot_hw: layout must be 0 (planar) or 1 (channel-minor)");
+    SBG_CHECK(N >= 1 && C >= 1 && HW >= 1, "dot_hw: bad sizes");
+    SBG_CHECK((int64_t)N * C <= INT32_MAX, "dot_hw: too many (sample, channel) pairs");
+    DotArgs p; p.u = u; p.v = v; p.partial = partial; p.N = N; p.C = C; p.HW = HW;
+    const bool fast = dot_fast(layout, C) && sbg_aligned16(u) && (!v || sbg_aligned16(v));
+    p.nsplit = dot_fast(layout, C) ? sbg_dot_hw_splits(layout, N, C, HW) : 1;
+    p.pix_per_split = DOT_PIX_PER_SPLIT;
+    hipStream_t s = (hipStream_t)stream;
+    if (!fast && p.nsplit > 1) {
+        // unaligned view of a channel-minor tensor: the generic kernel writes split 0 only; zero the others
+        if (hipMemsetAsync(partial, 0, sizeof(float) * (size_t)p.nsplit * N * C, s) != hipSuccess) return sbg_fail(SBG_ERR_LAUNCH, "dot_hw: memset failed");
+    }
+    if (dtype == SBG_F32) return run_dot<float>(p, layout, fast, s);
+    if (dtype == SBG_F16) return run_dot<f16_s>(p, layout, fast, s);
+    return run_dot<bf16_s>(p, layout, fast, s);
+}

@@ -88,6 +88,11 @@ def _run(x, b, xref, yref, dy, grad, cfg, fmt):
 
 
 def _sum_to_bias(t, dim):
+    """db = t summed over every dimension but `dim` (reference: bias_act.py:172-173); 4-D / dim 1 goes through the
+    HIP reduction sbg_dot_hw (fp32 accumulation), everything else is small and uses torch."""
+    if t.ndim == 4 and dim == 1 and t.device.type == "cuda":
+        from . import modulate
+        return modulate.dot_hw(t).sum(0).to(t.dtype)
     return t.sum([i for i in range(t.ndim) if i != dim])
 
 

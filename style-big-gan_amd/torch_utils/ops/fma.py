@@ -1,12 +1,21 @@
 """Fused multiply-add ``a * b + c`` with broadcast-aware gradients.
 
-Host-side mirror of ``stylegan2ada/torch_utils/ops/fma.py`` (``fma`` :15): used by the modulated convolution for
-``x * dcoefs + noise``.  The gradients reduce over the broadcast dimensions instead of materialising expanded tensors.
+Host-side mirror of ``stylegan2ada/torch_utils/ops/fma.py`` (``fma`` :15).  The shape the models use --
+``a`` [N, C, H, W] activations, ``b`` [N, C, 1, 1] per-sample channel scale, ``c`` [N, 1, H, W] per-pixel addend
+(train_parts/generators.py:84) -- runs in the HIP kernel ``sbg_scale_nc`` with reduction gradients from ``sbg_dot_hw``
+(see modulate.py); other broadcast patterns use torch.addcmul on the device with the reference's un-broadcasting
+gradient rule (:49-58).
 """
 import torch
 
+from . import modulate
+
 
 def fma(a, b, c):   # => a * b + c
+    if (a.ndim == 4 and b.ndim == 4 and c.ndim == 4 and a.device.type == "cuda"
+            and tuple(b.shape) == (a.shape[0], a.shape[1], 1, 1)
+            and tuple(c.shape) == (a.shape[0], 1, a.shape[2], a.shape[3])):
+        return modulate.scale_nc(a, b.reshape(a.shape[0], a.shape[1]), c)
     return _FusedMultiplyAdd.apply(a, b, c)
 
 

@@ -1,0 +1,269 @@
+"""Discriminators (host-side modules over the HIP op layer).
+
+Mirror of the registry surface and module tree of the reference's ``train_parts/discriminators.py``: registry
+``discriminators`` with ``@discriminators.add_to_registry("sg2_classic" | "cnn32_dcgan" | "cnn48_dcgan" | "big_gan")``; for
+StyleGAN2 ``DiscriminatorBlock`` (:211), ``MinibatchStdLayer`` (:307), ``DiscriminatorEpilogue`` (:332) and
+``Discriminator`` (:403) keep constructor arguments, parameter / buffer names and forward semantics, so state_dicts
+interchange with the reference.  Reduced-precision blocks run in ``generators.LOW_PRECISION`` (bf16 by default),
+channel-minor, on the hand-written kernels behind ``torch_utils.ops``.
+"""
+import numpy as np
+import torch
+
+from .. import utils
+from ..torch_utils import misc
+from ..torch_utils.ops import upfirdn2d
+from . import generators as _g
+from .generators import Conv2dLayer, FullyConnectedLayer, MappingNetwork
+
+discriminators = utils.ClassRegistry()
+
+
+def _attention_module(channels):
+    from ..biggan.layers import Attention
+    return Attention(channels)
+
+
+class DiscriminatorBlock(torch.nn.Module):
+    def __init__(self,
+        in_channels         = None,         # 0 = first block
+        tmp_channels        = None,
+        out_channels        = None,
+        resolution          = None,
+        img_channels        = None,
+        first_layer_idx     = None,
+        architecture        = 'resnet',     # 'orig', 'skip', 'resnet'
+        attention           = False,
+        activation          = 'lrelu',
+        resample_filter     = (1,3,3,1),
+        conv_clamp          = None,
+        use_fp16            = False,        # run this block in LOW_PRECISION
+        fp16_channels_last  = False,        # kept for config parity (reduced-precision blocks are always channel-minor)
+        freeze_layers       = 0,            # Freeze-D
+    ):
+        assert None not in (in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx)
+        assert in_channels in [0, tmp_channels]
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.first_layer_idx = first_layer_idx
+        self.architecture = architecture
+        self.use_fp16 = use_fp16
+        self.channels_last = bool(use_fp16)
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(list(resample_filter)))
+        self.attention = _attention_module(out_channels) if attention else None
+
+        self.num_layers = 0
+
+        def next_trainable():
+            trainable = (self.first_layer_idx + self.num_layers) >= freeze_layers
+            self.num_layers += 1
+            return trainable
+
+        common = dict(activation=activation, conv_clamp=conv_clamp, channels_last=self.channels_last)
+        if in_channels == 0 or architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, trainable=next_trainable(), **common)
+        self.conv0 = Conv2dLayer(tmp_channels, tmp_channels, kernel_size=3, trainable=next_trainable(), **common)
+        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, down=2, trainable=next_trainable(),
+                                 resample_filter=resample_filter, **common)
+        if architecture == 'resnet':
+            self.skip = Conv2dLayer(tmp_channels, out_channels, kernel_size=1, bias=False, down=2, trainable=next_trainable(),
+                                    resample_filter=resample_filter, channels_last=self.channels_last)
+
+    def forward(self, x, img, force_fp32=False):
+        reduced = self.use_fp16 and not force_fp32
+        dtype = _g.LOW_PRECISION if reduced else torch.float32
+        fmt = torch.channels_last if reduced else torch.contiguous_format
+
+        if x is not None:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+            x = x.to(dtype=dtype, memory_format=fmt)
+
+        if self.in_channels == 0 or self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            img = img.to(dtype=dtype, memory_format=fmt)
+            y = self.fromrgb(img)
+            x = x + y if x is not None else y
+            img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
+
+        if self.architecture == 'resnet':
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x)
+            x = self.conv1(x, gain=np.sqrt(0.5))
+            x = y.add_(x)
+        else:
+            x = self.conv0(x)
+            x = self.conv1(x)
+
+        if self.attention is not None:
+            x = self.attention(x.to(torch.float32)).to(dtype)
+
+        assert x.dtype == dtype
+        return x, img
+
+
+class MinibatchStdLayer(torch.nn.Module):
+    """Appends `num_channels` feature maps holding the per-group standard deviation (reference :307-328)."""
+
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        self.group_size = group_size
+        self.num_channels = num_channels
+
+    def forward(self, x):
+        N, C, H, W = x.shape
+        G = min(int(self.group_size), N) if self.group_size is not None else N
+        F = self.num_channels
+        c = C // F
+        y = x.reshape(G, -1, F, c, H, W)
+        y = y - y.mean(dim=0)
+        y = y.square().mean(dim=0)
+        y = (y + 1e-8).sqrt()
+        y = y.mean(dim=[2, 3, 4])
+        y = y.reshape(-1, F, 1, 1)
+        y = y.repeat(G, 1, H, W)
+        return torch.cat([x, y], dim=1)
+
+
+class DiscriminatorEpilogue(torch.nn.Module):
+    def __init__(self,
+        in_channels         = None,
+        cmap_dim            = None,     # 0 = no label
+        resolution          = None,
+        img_channels        = None,
+        architecture        = 'resnet',
+        mbstd_group_size    = 4,        # None = entire minibatch
+        mbstd_num_channels  = 1,        # 0 = disable
+        activation          = 'lrelu',
+        conv_clamp          = None,
+    ):
+        assert None not in (in_channels, cmap_dim, resolution, img_channels)
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.cmap_dim = cmap_dim
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.architecture = architecture
+        if architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, in_channels, kernel_size=1, activation=activation)
+        self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels) if mbstd_num_channels > 0 else None
+        self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
+        self.fc = FullyConnectedLayer(in_channels * (resolution ** 2), in_channels, activation=activation)
+        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+
+    def forward(self, x, img, cmap, force_fp32=False):
+        misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+        dtype, fmt = torch.float32, torch.contiguous_format     # the epilogue always runs in fp32 (reference :366-367)
+        x = x.to(dtype=dtype, memory_format=fmt)
+        if self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            x = x + self.fromrgb(img.to(dtype=dtype, memory_format=fmt))
+        if self.mbstd is not None:
+            x = self.mbstd(x)
+        x = self.conv(x)
+        x = self.fc(x.flatten(1))
+        x = self.out(x)
+        if self.cmap_dim > 0:
+            misc.assert_shape(cmap, [None, self.cmap_dim])
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
+        assert x.dtype == dtype
+        return x
+
+
+Mappingkwargs = discriminators.make_dataclass_from_init(MappingNetwork.__init__, 'Mappingkwargs', None)
+Discblockkwargs = discriminators.make_dataclass_from_init(DiscriminatorBlock.__init__, 'Discblockkwargs', None)
+Discepilogkwargs = discriminators.make_dataclass_from_init(DiscriminatorEpilogue.__init__, 'Discepilogkwargs', None)
+
+
+@discriminators.add_to_registry("sg2_classic")
+class Discriminator(torch.nn.Module):
+    def __init__(self,
+        c_dim               = None,
+        img_resolution      = None,
+        img_channels        = None,
+        attentions          = (),
+        architecture        = 'resnet',
+        channel_base        = 32768,
+        channel_max         = 512,
+        num_fp16_res        = 0,        # run the N highest resolutions in LOW_PRECISION
+        conv_clamp          = None,
+        cmap_dim            = None,     # None = default
+        block_kwargs        = Discblockkwargs(),
+        mapping_kwargs      = Mappingkwargs(),
+        epilogue_kwargs     = Discepilogkwargs(),
+    ):
+        assert img_resolution is not None and img_channels is not None
+        super().__init__()
+        self.c_dim = c_dim
+        self.img_resolution = img_resolution
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.img_channels = img_channels
+        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
+        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        if cmap_dim is None:
+            cmap_dim = channels[4]
+        if c_dim == 0:
+            cmap_dim = 0
+
+        common = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        bk = dict(block_kwargs.items()) if block_kwargs is not None else {}
+        layer_idx = 0
+        for res in self.block_resolutions:
+            bk.update(in_channels=(channels[res] if res < img_resolution else 0), tmp_channels=channels[res],
+                      out_channels=channels[res // 2], resolution=res, first_layer_idx=layer_idx,
+                      use_fp16=(res >= fp16_resolution), attention=(res in attentions))
+            bk.update(common)
+            block = DiscriminatorBlock(**bk)
+            setattr(self, f'b{res}', block)
+            layer_idx += block.num_layers
+        if c_dim is not None and c_dim > 0:
+            mk = dict(mapping_kwargs.items()) if mapping_kwargs is not None else {}
+            mk.update(z_dim=0, c_dim=c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None)
+            self.mapping = MappingNetwork(**mk)
+        ek = dict(epilogue_kwargs.items()) if epilogue_kwargs is not None else {}
+        ek.update(in_channels=channels[4], cmap_dim=cmap_dim, resolution=4)
+        ek.update(common)
+        self.b4 = DiscriminatorEpilogue(**ek)
+
+    def forward(self, img, c, **block_kwargs):
+        x = None
+        for res in self.block_resolutions:
+            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+        cmap = self.mapping(None, c) if (self.c_dim is not None and self.c_dim > 0) else None
+        return self.b4(x, img, cmap)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# DCGAN (plumbing config: stock torch.nn layers, CPU eager -- reference :471-513)
+
+class Discriminator_dcgan(torch.nn.Module):
+    """four stride-2 5x5 convolutions (LeakyReLU, BatchNorm after all but the first) then a linear logit"""
+
+    def __init__(self, M):
+        super().__init__()
+        layers = []
+        for i, (cin, cout) in enumerate([(3, 64), (64, 128), (128, 256), (256, 512)]):
+            layers += [torch.nn.Conv2d(cin, cout, 5, 2, 2, bias=False), torch.nn.LeakyReLU(0.2, inplace=True)]
+            if i > 0:
+                layers.append(torch.nn.BatchNorm2d(cout))
+        self.main = torch.nn.Sequential(*layers)
+        self.linear = torch.nn.Linear(M // 16 * M // 16 * 512, 1)
+
+    def forward(self, x, c):
+        return self.linear(torch.flatten(self.main(x), start_dim=1))
+
+
+@discriminators.add_to_registry("cnn32_dcgan")
+class Discriminator32_dcgan(Discriminator_dcgan):
+    def __init__(self, *args, **kwargs):
+        super().__init__(M=32)
+
+
+@discriminators.add_to_registry("cnn48_dcgan")
+class Discriminator48_dcgan(Discriminator_dcgan):
+    def __init__(self):
+        super().__init__(M=48)

@@ -1,0 +1,500 @@
+"""Generators (host-side modules over the HIP op layer).
+
+Mirror of the registry surface and module tree of the reference's ``train_parts/generators.py``: the registry
+``generators`` with ``@generators.add_to_registry("sg2_classic" | "cnn32_dcgan" | "cnn48_dcgan" | "big_gan")``, and for
+StyleGAN2 the modules ``FullyConnectedLayer`` (:105), ``Conv2dLayer`` (:139), ``MappingNetwork`` (:190),
+``SynthesisLayer`` (:273), ``ToRGBLayer`` (:334), ``SynthesisBlock`` (:354), ``SynthesisNetwork`` (:464) and
+``Generator`` (:533) with identical constructor arguments, parameter / buffer names (state_dicts interchange with the
+reference) and forward semantics.  What differs is underneath:
+
+* every tensor op on the hot path is a hand-written gfx950 kernel (bias_act, upfirdn2d, implicit-GEMM convolutions,
+  per-sample scaling) reached through ``torch_utils.ops``;
+* the reduced-precision blocks (``use_fp16`` in the reference) run in ``LOW_PRECISION`` = bfloat16 by default --
+  the matrix-core dtype of choice on MI355X -- and always channel-minor; ``set_low_precision(torch.float16)``
+  restores the reference's dtype;
+* ``modulated_conv2d`` never materialises per-sample weights: demodulation coefficients come from
+  ``styles^2 @ sum_kk(w^2)^T`` (algebraically the reference's :71-76) and both ``fused_modconv`` settings scale
+  activations around one shared-weight convolution (the reference's training path :79-88; its eval-only grouped
+  convolution :90-100 computes the same function).
+"""
+import numpy as np
+import torch
+
+from .. import utils
+from ..torch_utils import misc
+from ..torch_utils.ops import bias_act, conv2d_resample, modulate, upfirdn2d
+
+generators = utils.ClassRegistry()
+
+LOW_PRECISION = torch.bfloat16
+
+
+def set_low_precision(dtype):
+    """dtype used by blocks constructed with use_fp16=True: torch.bfloat16 (default) or torch.float16"""
+    global LOW_PRECISION
+    assert dtype in (torch.bfloat16, torch.float16)
+    LOW_PRECISION = dtype
+
+
+def low_precision():
+    return LOW_PRECISION
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# StyleGAN2
+
+@misc.profiled_function
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+def demod_coefficients(weight, styles):
+    """dcoefs[n, o] = rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[n,i])^2 + 1e-8), as a [N, I] x [I, O] product (fp32)."""
+    w2 = weight.to(torch.float32).square().sum(dim=[2, 3])            # [O, I]
+    return (styles.to(torch.float32).square() @ w2.t() + 1e-8).rsqrt()   # [N, O]
+
+
+@misc.profiled_function
+def modulated_conv2d(
+    x,                          # [N, Cin, H, W]
+    weight,                     # [Cout, Cin, kh, kw]
+    styles,                     # [N, Cin] modulation coefficients
+    noise           = None,     # optional noise added to the output
+    up              = 1,
+    down            = 1,
+    padding         = 0,        # w.r.t. the upsampled image
+    resample_filter = None,     # from upfirdn2d.setup_filter()
+    demodulate      = True,
+    flip_weight     = True,     # False = convolution, True = correlation
+    fused_modconv   = True,     # accepted for API parity; both settings run the same kernels (see module docstring)
+):
+    n = x.shape[0]
+    cout, cin, kh, kw = weight.shape
+    misc.assert_shape(x, [n, cin, None, None])
+    misc.assert_shape(styles, [n, cin])
+
+    if x.dtype == torch.float16 and demodulate:     # keep fp16 activations in range (reference :63-65); bf16 needs none
+        weight = weight * (1 / np.sqrt(cin * kh * kw) / weight.norm(float("inf"), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float("inf"), dim=1, keepdim=True)
+
+    dcoefs = demod_coefficients(weight, styles) if demodulate else None
+    x = modulate.scale_nc(x, styles)
+    x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down,
+                                        padding=padding, flip_weight=flip_weight)
+    if demodulate:
+        x = modulate.scale_nc(x, dcoefs, noise)
+    elif noise is not None:
+        x = x.add_(noise.to(x.dtype))
+    return x
+
+
+class FullyConnectedLayer(torch.nn.Module):
+    def __init__(self,
+        in_features,
+        out_features,
+        bias            = True,
+        activation      = 'linear',
+        lr_multiplier   = 1,
+        bias_init       = 0,
+    ):
+        super().__init__()
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+
+class Conv2dLayer(torch.nn.Module):
+    def __init__(self,
+        in_channels,
+        out_channels,
+        kernel_size,
+        bias            = True,
+        activation      = 'linear',
+        up              = 1,
+        down            = 1,
+        resample_filter = [1,3,3,1],
+        conv_clamp      = None,
+        channels_last   = False,
+        trainable       = True,
+    ):
+        super().__init__()
+        self.activation = activation
+        self.up = up
+        self.down = down
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt)
+        bias = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(bias) if bias is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if bias is not None:
+                self.register_buffer('bias', bias)
+            else:
+                self.bias = None
+
+    def forward(self, x, gain=1):
+        w = self.weight * self.weight_gain
+        b = self.bias.to(x.dtype) if self.bias is not None else None
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
+
+class MappingNetwork(torch.nn.Module):
+    def __init__(self,
+        z_dim           = None,     # 0 = no latent
+        c_dim           = None,     # 0 = no label
+        w_dim           = None,
+        num_ws          = None,     # None = do not broadcast
+        num_layers      = 8,
+        embed_features  = None,     # None = w_dim
+        layer_features  = None,     # None = w_dim
+        activation      = 'lrelu',
+        lr_multiplier   = 0.01,
+        w_avg_beta      = 0.995,    # None = do not track
+    ):
+        assert z_dim is not None and c_dim is not None and w_dim is not None
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.num_ws, self.num_layers, self.w_avg_beta = num_ws, num_layers, w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        widths = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(widths[idx], widths[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
+        x = None
+        if self.z_dim > 0:
+            misc.assert_shape(z, [None, self.z_dim])
+            x = normalize_2nd_moment(z.to(torch.float32))
+        if self.c_dim > 0:
+            misc.assert_shape(c, [None, self.c_dim])
+            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+            x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            assert self.w_avg_beta is not None
+            if self.num_ws is None or truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class SynthesisLayer(torch.nn.Module):
+    def __init__(self,
+        in_channels     = None,
+        out_channels    = None,
+        w_dim           = None,
+        resolution      = None,
+        kernel_size     = 3,
+        up              = 1,
+        use_noise       = True,
+        activation      = 'lrelu',
+        resample_filter = (1,3,3,1),
+        conv_clamp      = None,
+        channels_last   = False,
+    ):
+        assert None not in (in_channels, out_channels, w_dim, resolution)
+        super().__init__()
+        self.resolution = resolution
+        self.up = up
+        self.use_noise = use_noise
+        self.activation = activation
+        self.conv_clamp = conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(list(resample_filter)))
+        self.padding = kernel_size // 2
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+        assert noise_mode in ['random', 'const', 'none']
+        misc.assert_shape(x, [None, self.weight.shape[1], self.resolution // self.up, self.resolution // self.up])
+        styles = self.affine(w)
+        noise = None
+        if self.use_noise and noise_mode == 'random':
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        if self.use_noise and noise_mode == 'const':
+            noise = self.noise_const * self.noise_strength
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
+                             resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
+
+class ToRGBLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.conv_clamp = conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+
+    def forward(self, x, w, fused_modconv=True):
+        styles = self.affine(w) * self.weight_gain
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+
+
+Synthlayerkwargs = generators.make_dataclass_from_init(SynthesisLayer.__init__, 'Synthlayerkwargs', None)
+
+
+def _attention_module(channels):
+    from ..biggan.layers import Attention
+    return Attention(channels)
+
+
+class SynthesisBlock(torch.nn.Module):
+    def __init__(self,
+        in_channels         = None,         # 0 = first block
+        out_channels        = None,
+        w_dim               = None,
+        resolution          = None,
+        img_channels        = None,
+        is_last             = None,
+        architecture        = 'skip',       # 'orig', 'skip', 'resnet'
+        resample_filter     = (1,3,3,1),
+        conv_clamp          = None,
+        use_fp16            = False,        # run this block in LOW_PRECISION
+        fp16_channels_last  = False,        # kept for config parity; reduced-precision blocks are always channel-minor here
+        attention           = False,        # self-attention at the end of the block
+        layer_kwargs        = Synthlayerkwargs(),
+    ):
+        assert None not in (in_channels, out_channels, w_dim, resolution, img_channels, is_last)
+        assert architecture in ['orig', 'skip', 'resnet']
+        super().__init__()
+        self.in_channels = in_channels
+        self.w_dim = w_dim
+        self.resolution = resolution
+        self.img_channels = img_channels
+        self.is_last = is_last
+        self.architecture = architecture
+        self.use_fp16 = use_fp16
+        self.channels_last = bool(use_fp16)
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(list(resample_filter)))
+        self.num_conv = 0
+        self.num_torgb = 0
+        self.attention = _attention_module(out_channels) if attention else None
+
+        if in_channels == 0:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        lk = dict(layer_kwargs.items()) if layer_kwargs is not None else {}
+        lk.update(in_channels=in_channels, out_channels=out_channels, w_dim=w_dim, resolution=resolution, up=2,
+                  resample_filter=resample_filter, conv_clamp=conv_clamp, channels_last=self.channels_last)
+        if in_channels != 0:
+            self.conv0 = SynthesisLayer(**lk)
+            self.num_conv += 1
+        lk.update(in_channels=out_channels, up=1, resample_filter=[1, 3, 3, 1])
+        self.conv1 = SynthesisLayer(**lk)
+        self.num_conv += 1
+        if is_last or architecture == 'skip':
+            self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last)
+            self.num_torgb += 1
+        if in_channels != 0 and architecture == 'resnet':
+            self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
+                                    resample_filter=resample_filter, channels_last=self.channels_last)
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, **layer_kwargs):
+        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        w_iter = iter(ws.unbind(dim=1))
+        reduced = self.use_fp16 and not force_fp32
+        dtype = LOW_PRECISION if reduced else torch.float32
+        fmt = torch.channels_last if reduced else torch.contiguous_format
+        if fused_modconv is None:
+            fused_modconv = (not self.training) and (dtype == torch.float32 or int(x.shape[0]) == 1)
+
+        if self.in_channels == 0:
+            x = self.const.to(dtype=dtype, memory_format=fmt)
+            x = x.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
+            x = x.to(dtype=dtype, memory_format=fmt)
+
+        if self.in_channels == 0:
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+        elif self.architecture == 'resnet':
+            y = self.skip(x, gain=np.sqrt(0.5))
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
+            x = y.add_(x)
+        else:
+            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+
+        if self.attention is not None:
+            x = self.attention(x.to(torch.float32)).to(dtype)
+
+        if img is not None:
+            misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        if self.is_last or self.architecture == 'skip':
+            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
+            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            img = img.add_(y) if img is not None else y
+
+        assert x.dtype == dtype
+        assert img is None or img.dtype == torch.float32
+        return x, img
+
+
+Synthblockkwargs = generators.make_dataclass_from_init(SynthesisBlock.__init__, 'Synthblockkwargs', None)
+
+
+class SynthesisNetwork(torch.nn.Module):
+    def __init__(self,
+        w_dim           = None,
+        img_resolution  = None,
+        img_channels    = None,
+        channel_base    = 32768,
+        channel_max     = 512,
+        num_fp16_res    = 0,        # run the N highest resolutions in LOW_PRECISION
+        attentions      = (),
+        block_kwargs    = Synthblockkwargs(),
+    ):
+        assert None not in (w_dim, img_resolution, img_channels)
+        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim = w_dim
+        self.img_resolution = img_resolution
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.img_channels = img_channels
+        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
+        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        bk = dict(block_kwargs.items()) if block_kwargs is not None else {}
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            bk.update(in_channels=(channels[res // 2] if res > 4 else 0), out_channels=channels[res], w_dim=w_dim, resolution=res,
+                      img_channels=img_channels, is_last=(res == img_resolution), use_fp16=(res >= fp16_resolution),
+                      attention=(res in attentions))
+            block = SynthesisBlock(**bk)
+            self.num_ws += block.num_conv
+            if res == img_resolution:
+                self.num_ws += block.num_torgb
+            setattr(self, f'b{res}', block)
+
+    def forward(self, ws, **block_kwargs):
+        misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+        ws = ws.to(torch.float32)
+        per_block, w_idx = [], 0
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            per_block.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
+            w_idx += block.num_conv
+        x = img = None
+        for res, cur_ws in zip(self.block_resolutions, per_block):
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
+        return img
+
+
+Mappingkwargs = generators.make_dataclass_from_init(MappingNetwork.__init__, 'Mappingkwargs', None)
+Synthesiskwargs = generators.make_dataclass_from_init(SynthesisNetwork.__init__, 'Synthesiskwargs', None)
+
+
+@generators.add_to_registry("sg2_classic")
+class Generator(torch.nn.Module):
+    def __init__(self,
+        z_dim               = 128,
+        c_dim               = None,
+        w_dim               = 128,
+        img_resolution      = None,
+        img_channels        = None,
+        attentions          = (),
+        mapping_kwargs      = Mappingkwargs(),
+        synthesis_kwargs    = Synthesiskwargs(),
+    ):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        sk = dict(synthesis_kwargs.items()) if synthesis_kwargs is not None else {}
+        sk.update(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, attentions=attentions)
+        self.synthesis = SynthesisNetwork(**sk)
+        self.num_ws = self.synthesis.num_ws
+        mk = dict(mapping_kwargs.items()) if mapping_kwargs is not None else {}
+        mk.update(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws)
+        self.mapping = MappingNetwork(**mk)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        return self.synthesis(ws, **synthesis_kwargs)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# DCGAN (plumbing config `configs/dcgan.yaml`: stock torch.nn layers, runs on CPU eager -- reference :569-606)
+
+def _dcgan_up(cin, cout, k, stride, pad, last=False):
+    conv = torch.nn.ConvTranspose2d(cin, cout, k, stride, pad, bias=False)
+    return [conv, torch.nn.Tanh()] if last else [conv, torch.nn.BatchNorm2d(cout), torch.nn.ReLU(True)]
+
+
+class Generator_dcgan(torch.nn.Module):
+    """z -> [z_dim, 1, 1] -> M x M -> four stride-2 transposed 4x4 convolutions -> 16M x 16M RGB in [-1, 1]"""
+
+    def __init__(self, z_dim, M):
+        super().__init__()
+        self.z_dim = z_dim
+        layers = _dcgan_up(z_dim, 1024, M, 1, 0)
+        for cin, cout in [(1024, 512), (512, 256), (256, 128)]:
+            layers += _dcgan_up(cin, cout, 4, 2, 1)
+        layers += _dcgan_up(128, 3, 4, 2, 1, last=True)
+        self.main = torch.nn.Sequential(*layers)
+
+    def forward(self, z, c, noise_mode=None):
+        return self.main(z.view(-1, self.z_dim, 1, 1))
+
+
+@generators.add_to_registry("cnn32_dcgan")
+class Generator32_dcgan(Generator_dcgan):
+    def __init__(self, z_dim, c_dim, img_resolution, *args, **kwargs):
+        super().__init__(z_dim, M=2)
+        self.c_dim = c_dim
+        self.img_resolution = img_resolution
+
+
+@generators.add_to_registry("cnn48_dcgan")
+class Generator48_dcgan(Generator_dcgan):
+    def __init__(self, z_dim):
+        super().__init__(z_dim, M=4)
