@@ -145,6 +145,27 @@ int sbg_dot_hw_splits(int layout, int N, int C, int64_t HW);
 int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layout,
                int N, int C, int64_t HW, sbg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * In-process launch timing (measurement only; bench.py's roofline figures come from here).
+ * While enabled, every kernel launch of this library is bracketed by two hipEvents recorded on the launch stream
+ * and logged with its algorithmic flops / bytes.  sbg_prof_fetch() synchronises the logged events, writes up to `max`
+ * records (oldest first) with their measured duration, clears the log and returns the number written
+ * (or the number pending when out == NULL). */
+enum sbg_kernel_kind {
+    SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7
+};
+typedef struct sbg_prof_record {
+    int    kind;            /* enum sbg_kernel_kind */
+    int    dims[7];         /* kernel specific shape key (see each kernel's source) */
+    double flops;           /* algorithmic floating point operations of the launch (2 x MACs) */
+    double bytes;           /* algorithmic HBM bytes of the launch */
+    float  ms;              /* measured duration */
+    int    pad;
+} sbg_prof_record;
+int sbg_prof_enable(int on);
+int sbg_prof_fetch(sbg_prof_record* out, int max);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,13 @@ class WgradParams(ctypes.Structure):
     ]
 
 
+class ProfRecord(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("dims", ctypes.c_int * 7), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
+                ("ms", ctypes.c_float), ("pad", ctypes.c_int)]
+
+
+KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw"}
+
 _lib = None
 _lock = threading.Lock()
 
@@ -83,6 +90,8 @@ SYMBOLS = [
     ("sbg_scale_nc", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_void_p]),
     ("sbg_dot_hw_splits", _c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64]),
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
+    ("sbg_prof_enable", _c.c_int, [_c.c_int]),
+    ("sbg_prof_fetch", _c.c_int, [_c.POINTER(ProfRecord), _c.c_int]),
 ]
 
 
@@ -127,3 +136,19 @@ def require_cuda(t, what):
         raise RuntimeError(
             f"{what}: tensor is on '{t.device}'. style_big_gan_amd ops run only as HIP kernels on a ROCm device "
             "(device type 'cuda'); there is no CPU path in the product (the CPU restatement lives in oracle/ and is test-only).")
+
+
+def prof_enable(on):
+    """switch the library's per-launch hipEvent timing on / off (measurement only)"""
+    return load().sbg_prof_enable(int(bool(on)))
+
+
+def prof_fetch():
+    """-> list of dicts (kind, dims, flops, bytes, ms) for every launch logged since the last fetch"""
+    lib = load()
+    n = lib.sbg_prof_fetch(None, 0)
+    if n <= 0:
+        return []
+    buf = (ProfRecord * n)()
+    n = lib.sbg_prof_fetch(buf, n)
+    return [dict(kind=KERNEL_KINDS.get(r.kind, str(r.kind)), dims=tuple(r.dims), flops=r.flops, bytes=r.bytes, ms=r.ms) for r in buf[:n]]

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(256) void bias_act_scalar(BiasActArgs p)
 template <class T, int A>
 static int launch_bias_act(const BiasActArgs& p, bool vec, hipStream_t stream)
 {
+    const int es = sizeof(T) == 4 ? 4 : 2;
+    const int streams = 2 + (p.xref ? 1 : 0) + (p.yref ? 1 : 0) + (p.dy ? 1 : 0);
+    SbgProfScope prof(stream, SBG_K_BIAS_ACT, 0.0, (double)p.sizeX * es * streams, {(int)p.sizeX, p.grad, A, es});
     if (vec) {
         unsigned grid = sbg_stream_grid((p.sizeX >> 3) + 1, 256);
         hipLaunchKernelGGL((bias_act_vec8<T, A>), dim3(grid), dim3(256), 0, stream, p);

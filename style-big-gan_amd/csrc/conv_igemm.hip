@@ -214,6 +214,10 @@ static int launch_conv(ConvArgs& a, hipStream_t stream)
     if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
     constexpr int lds = 2 * (4 * BC * 16 + 4 * BP * 16);
     auto kern = conv_igemm_kernel<MF, BC, BP, WGC, WGP>;
+    const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
+    SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
+                      2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
+                      {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, BC * 1000 + BP});
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;

@@ -256,6 +256,9 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t stream)
             return sbg_fail(SBG_ERR_LAUNCH, "conv2d_wgrad: cannot raise the dynamic LDS limit to %d bytes", lds);
         attr_set = true;
     }
+    SbgProfScope prof(stream, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
+                      2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
+                      {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, BCA * 1000 + BCB});
     hipLaunchKernelGGL(kern, dim3(a.atiles, a.btiles, a.nsplit), dim3(256), lds, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
@@ -299,6 +302,7 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
         }
     }
     if (a.nsplit > 1) {
+        SbgProfScope prof(s, SBG_K_WGRAD_REDUCE, 0.0, 4.0 * out_n * (a.nsplit + 1), {(int)out_n, a.nsplit});
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(sbg_stream_grid(out_n, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
         SBG_HIP_LAUNCH_CHECK();
     }

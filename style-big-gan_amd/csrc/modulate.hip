@@ -151,6 +151,8 @@ template <class T>
 static int run_scale(const ScaleArgs& a0, int layout, bool vec, hipStream_t s)
 {
     ScaleArgs a = a0;
+    const double es = sizeof(T) == 4 ? 4 : 2;
+    SbgProfScope prof(s, SBG_K_SCALE_NC, 0.0, 2.0 * es * a.N * (double)a.C * a.HW, {a.N, a.C, (int)a.HW, layout});
     if (vec) {
         a.total = (int64_t)a.N * a.HW * (a.C >> 3);
         hipLaunchKernelGGL((scale_nc_cminor8<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, s, a);
@@ -165,6 +167,8 @@ static int run_scale(const ScaleArgs& a0, int layout, bool vec, hipStream_t s)
 template <class T>
 static int run_dot(const DotArgs& a, int layout, bool fast, hipStream_t s)
 {
+    const double es = sizeof(T) == 4 ? 4 : 2;
+    SbgProfScope prof(s, SBG_K_DOT_HW, 0.0, (a.v ? 2.0 : 1.0) * es * a.N * (double)a.C * a.HW, {a.N, a.C, (int)a.HW, layout});
     if (fast) hipLaunchKernelGGL((dot_hw_cminor8<T>), dim3(a.N, a.nsplit), dim3(256), 0, s, a);
     else      hipLaunchKernelGGL((dot_hw_generic<T>), dim3((unsigned)((int64_t)a.N * a.C)), dim3(256), 0, s, a, layout);
     SBG_HIP_LAUNCH_CHECK();

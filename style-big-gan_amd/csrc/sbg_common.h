@@ -108,3 +108,17 @@ static inline unsigned sbg_stream_grid(int64_t work_items, int block)
     const int64_t cap = 256 * 8;
     return (unsigned)(need < cap ? need : cap);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Launch timing (see sbg_prof_* in include/sbg_hip.h).  Usage: { SbgProfScope prof(stream, kind, flops, bytes, dims); launch; }
+bool sbg_prof_on();
+int  sbg_prof_open(hipStream_t s, int kind, double flops, double bytes, const int* dims, int ndims);
+void sbg_prof_close(hipStream_t s, int slot);
+
+struct SbgProfScope {
+    hipStream_t s; int slot;
+    SbgProfScope(hipStream_t stream, int kind, double flops, double bytes, std::initializer_list<int> dims) : s(stream), slot(-1) {
+        if (sbg_prof_on()) slot = sbg_prof_open(stream, kind, flops, bytes, dims.begin(), (int)dims.size());
+    }
+    ~SbgProfScope() { if (slot >= 0) sbg_prof_close(s, slot); }
+};

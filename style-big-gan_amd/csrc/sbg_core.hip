@@ -10,3 +10,69 @@ std::string& sbg_err_slot()
 extern "C" int sbg_version(void) { return 1; }
 
 extern "C" const char* sbg_last_error(void) { return sbg_err_slot().c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// Launch timing log.
+#include <vector>
+#include <mutex>
+#include <atomic>
+
+namespace {
+struct ProfEntry { sbg_prof_record rec; hipEvent_t start, stop; bool closed; };
+std::mutex g_prof_mu;
+std::vector<ProfEntry> g_prof_log;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+std::atomic<int> g_prof_enabled{0};
+const size_t kProfMax = 1 << 20;
+}
+
+bool sbg_prof_on() { return g_prof_enabled.load(std::memory_order_relaxed) != 0; }
+
+int sbg_prof_open(hipStream_t s, int kind, double flops, double bytes, const int* dims, int ndims)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_log.size() >= kProfMax) return -1;
+    ProfEntry e;
+    e.rec.kind = kind; e.rec.flops = flops; e.rec.bytes = bytes; e.rec.ms = 0.f; e.rec.pad = 0;
+    for (int i = 0; i < 7; i++) e.rec.dims[i] = i < ndims ? dims[i] : 0;
+    if (!g_prof_pool.empty()) { e.start = g_prof_pool.back().first; e.stop = g_prof_pool.back().second; g_prof_pool.pop_back(); }
+    else {
+        if (hipEventCreate(&e.start) != hipSuccess) return -1;
+        if (hipEventCreate(&e.stop) != hipSuccess) { (void)hipEventDestroy(e.start); return -1; }
+    }
+    e.closed = false;
+    (void)hipEventRecord(e.start, s);
+    g_prof_log.push_back(e);
+    return (int)g_prof_log.size() - 1;
+}
+
+void sbg_prof_close(hipStream_t s, int slot)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < 0 || slot >= (int)g_prof_log.size()) return;
+    (void)hipEventRecord(g_prof_log[slot].stop, s);
+    g_prof_log[slot].closed = true;
+}
+
+extern "C" int sbg_prof_enable(int on)
+{
+    return g_prof_enabled.exchange(on ? 1 : 0);
+}
+
+extern "C" int sbg_prof_fetch(sbg_prof_record* out, int max)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (out == nullptr) return (int)g_prof_log.size();
+    int n = 0;
+    for (auto& e : g_prof_log) {
+        if (e.closed) {
+            (void)hipEventSynchronize(e.stop);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e.start, e.stop) == hipSuccess) e.rec.ms = ms;
+        }
+        if (n < max) out[n++] = e.rec;
+        g_prof_pool.emplace_back(e.start, e.stop);
+    }
+    g_prof_log.clear();
+    return n;
+}

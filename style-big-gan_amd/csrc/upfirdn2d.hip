@@ -98,6 +98,10 @@ template <class T>
 static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, hipStream_t stream)
 {
     UpfirdnArgs a = a0;
+    const double es = sizeof(T) == 4 ? 4 : 2;
+    SbgProfScope prof(stream, SBG_K_UPFIRDN2D, 0.0,
+                      es * ((double)a.N * a.C * a.inH * a.inW + (double)a.N * a.C * a.outH * a.outW),
+                      {a.N, a.C, a.inH, a.inW, a.outH, a.outW, a.upx * 16 + a.downx});
     if (vec8) {
         a.total = (int64_t)a.N * a.outH * a.outW * (a.C >> 3);
         hipLaunchKernelGGL((upfirdn2d_kernel<T, 8>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a);

@@ -1,0 +1,237 @@
+"""Generate the golden fixtures in tests/golden/*.npz by running the REFERENCE on CPU.
+
+Run in the dev container only (the reference checkout does not travel to the GPU box):
+
+    PYTHONPATH=/root/reference python tests/golden/make_golden.py
+
+It imports the reference's own eager CPU path -- ``stylegan2ada.torch_utils.ops.*`` (pure-PyTorch ``_ref`` branches),
+``stylegan2ada.training.networks`` (the vendored original whose hot functions are byte-identical to
+``train_parts/generators.py`` / ``discriminators.py`` but import without omegaconf) and ``biggan.layers`` -- feeds seeded
+inputs and stores inputs + outputs (+ gradients, + second-order gradients where the hot path needs them).  Fixtures are
+data only: tensors as float32 arrays and JSON-encoded argument lists.
+"""
+import itertools
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("SBG_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+from stylegan2ada.torch_utils.ops import bias_act as R_bias_act            # noqa: E402
+from stylegan2ada.torch_utils.ops import conv2d_resample as R_resample    # noqa: E402
+from stylegan2ada.torch_utils.ops import fma as R_fma                      # noqa: E402
+from stylegan2ada.torch_utils.ops import upfirdn2d as R_upfirdn2d          # noqa: E402
+from stylegan2ada.training import networks as R_net                        # noqa: E402
+import stylegan2ada.dnnlib as dnnlib                                        # noqa: E402
+
+SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466,
+        0.787641141030194, 0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578,
+        0.0017677118642428036, -0.007800708325034148]
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(np.float32) if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def save(name, arrays, meta):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
+    print(f"{name}: {len(arrays)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ---------------------------------------------------------------------------------------------------------------- ops
+
+def gen_upfirdn2d():
+    torch.manual_seed(100)
+    arrays, cases = {}, []
+    filters = {"k4": ([1, 3, 3, 1], {}), "sym6": (SYM6, {}), "none": (None, {}), "k4_flipped_gain2": ([1, 3, 3, 1], dict(flip_filter=True, gain=2))}
+    for fname, (taps, fkw) in filters.items():
+        f = R_upfirdn2d.setup_filter(taps, **fkw) if taps is not None else None
+        if f is not None:
+            arrays[f"f/{fname}"] = npy(f)
+    idx = 0
+    for shape in [(2, 3, 8, 8), (1, 4, 9, 9)]:
+        for fname in filters:
+            f = torch.from_numpy(arrays[f"f/{fname}"]) if f"f/{fname}" in arrays else None
+            for (up, down), padding, flip, gain in itertools.product([(1, 1), (2, 1), (1, 2), (2, 2)], [0, [2, 1, 2, 1], [-1, 2, 3, -1]], [False, True], [1, 4]):
+                fw = 1 if f is None else f.shape[-1]
+                p = [padding] * 4 if isinstance(padding, int) else padding
+                if shape[3] * up + p[0] + p[1] - fw < 0 or shape[2] * up + p[2] + p[3] - fw < 0:
+                    continue
+                x = torch.randn(shape, requires_grad=True)
+                y = R_upfirdn2d.upfirdn2d(x, f, up=up, down=down, padding=padding, flip_filter=flip, gain=gain, impl='ref')
+                dy = torch.randn_like(y).requires_grad_(True)
+                dx = torch.autograd.grad((y * dy).sum(), x, create_graph=True)[0]
+                v = torch.randn_like(x)
+                ddy = torch.autograd.grad((dx * v).sum(), dy)[0]       # grad-of-grad (w.r.t. dy)
+                key = f"c{idx}"
+                arrays.update({f"{key}/x": npy(x), f"{key}/y": npy(y), f"{key}/dy": npy(dy), f"{key}/dx": npy(dx), f"{key}/v": npy(v), f"{key}/ddy": npy(ddy)})
+                cases.append(dict(key=key, filter=fname, up=up, down=down, padding=padding, flip_filter=flip, gain=gain))
+                idx += 1
+    # wrappers
+    f = torch.from_numpy(arrays["f/k4"])
+    x = torch.randn(2, 3, 16, 16)
+    arrays["wrap/x"] = npy(x)
+    for name in ["filter2d", "upsample2d", "downsample2d"]:
+        arrays[f"wrap/{name}"] = npy(getattr(R_upfirdn2d, name)(x, f, impl='ref'))
+    save("upfirdn2d", arrays, dict(cases=cases, sym6=SYM6))
+
+
+def gen_bias_act():
+    torch.manual_seed(101)
+    arrays, cases = {}, []
+    idx = 0
+    for act, spec in R_bias_act.activation_funcs.items():
+        for shape in [(2, 5, 4, 4), (3, 7)]:
+            for use_b, clamp, gain in itertools.product([False, True], [None, 0.5], [None, 2.0]):
+                x = torch.randn(shape, requires_grad=True)
+                b = torch.randn(shape[1], requires_grad=True) if use_b else None
+                y = R_bias_act.bias_act(x, b, dim=1, act=act, clamp=clamp, gain=gain, impl='ref')
+                dy = torch.randn_like(y).requires_grad_(True)
+                ins = [x] + ([b] if use_b else [])
+                g = torch.autograd.grad((y * dy).sum(), ins, create_graph=True)
+                key = f"c{idx}"
+                arrays.update({f"{key}/x": npy(x), f"{key}/y": npy(y), f"{key}/dy": npy(dy), f"{key}/dx": npy(g[0])})
+                if use_b:
+                    arrays[f"{key}/b"] = npy(b); arrays[f"{key}/db"] = npy(g[1])
+                # second order: derivative of sum(dx * v) w.r.t. dy (always defined) and x (when it exists)
+                v = torch.randn_like(x)
+                arrays[f"{key}/v"] = npy(v)
+                g2 = torch.autograd.grad((g[0] * v).sum(), [dy, x], allow_unused=True)
+                arrays[f"{key}/d_dy"] = npy(g2[0])
+                if g2[1] is not None:
+                    arrays[f"{key}/d_x"] = npy(g2[1])
+                cases.append(dict(key=key, act=act, use_b=use_b, clamp=clamp, gain=gain))
+                idx += 1
+    table = {k: dict(def_alpha=float(v.def_alpha), def_gain=float(v.def_gain), cuda_idx=int(v.cuda_idx), ref=v.ref, has_2nd_grad=bool(v.has_2nd_grad))
+             for k, v in R_bias_act.activation_funcs.items()}
+    save("bias_act", arrays, dict(cases=cases, activation_funcs=table))
+
+
+def gen_conv2d_resample():
+    torch.manual_seed(102)
+    arrays, cases = {}, []
+    f = R_upfirdn2d.setup_filter([1, 3, 3, 1])
+    idx = 0
+    for k, (up, down), flip_weight, groups in itertools.product([1, 3], [(1, 1), (2, 1), (1, 2), (2, 2)], [True, False], [1, 2]):
+        x = torch.randn(2, 8, 8, 8, requires_grad=True)
+        w = (torch.randn(6, 8 // groups, k, k) / np.sqrt(8 * k * k)).requires_grad_(True)
+        y = R_resample.conv2d_resample(x, w, f=f, up=up, down=down, padding=k // 2, groups=groups, flip_weight=flip_weight)
+        dy = torch.randn_like(y)
+        dx, dw = torch.autograd.grad((y * dy).sum(), [x, w])
+        key = f"c{idx}"
+        arrays.update({f"{key}/x": npy(x), f"{key}/w": npy(w), f"{key}/y": npy(y), f"{key}/dy": npy(dy), f"{key}/dx": npy(dx), f"{key}/dw": npy(dw)})
+        cases.append(dict(key=key, k=k, up=up, down=down, flip_weight=flip_weight, groups=groups))
+        idx += 1
+    save("conv2d_resample", arrays, dict(cases=cases))
+
+
+def gen_modulated_conv2d():
+    torch.manual_seed(103)
+    arrays, cases = {}, []
+    f = R_upfirdn2d.setup_filter([1, 3, 3, 1])
+    idx = 0
+    for demodulate, fused, up, use_noise in itertools.product([True, False], [True, False], [1, 2], [False, True]):
+        x = torch.randn(2, 8, 8, 8, requires_grad=True)
+        w = torch.randn(6, 8, 3, 3, requires_grad=True)
+        s = (torch.randn(2, 8) + 1).requires_grad_(True)
+        noise = torch.randn(2, 1, 8 * up, 8 * up) if use_noise else None
+        y = R_net.modulated_conv2d(x=x, weight=w, styles=s, noise=noise, up=up, padding=1, resample_filter=f, demodulate=demodulate,
+                                   flip_weight=(up == 1), fused_modconv=fused)
+        dy = torch.randn_like(y)
+        g = torch.autograd.grad((y * dy).sum(), [x, w, s], create_graph=True)
+        # path-length style second order: d/d(styles) of |d y / d styles|^2, and R1 style: d/dw of |dx|^2
+        pl = torch.autograd.grad(g[2].square().sum() + g[0].square().sum(), [w, s])
+        key = f"c{idx}"
+        arrays.update({f"{key}/x": npy(x), f"{key}/w": npy(w), f"{key}/s": npy(s), f"{key}/y": npy(y), f"{key}/dy": npy(dy),
+                       f"{key}/dx": npy(g[0]), f"{key}/dw": npy(g[1]), f"{key}/ds": npy(g[2]), f"{key}/d2w": npy(pl[0]), f"{key}/d2s": npy(pl[1])})
+        if use_noise:
+            arrays[f"{key}/noise"] = npy(noise)
+        cases.append(dict(key=key, demodulate=demodulate, fused_modconv=fused, up=up, use_noise=use_noise))
+        idx += 1
+    # fma
+    a, b, c = torch.randn(2, 4, 5, 5, requires_grad=True), torch.randn(2, 4, 1, 1, requires_grad=True), torch.randn(2, 1, 5, 5, requires_grad=True)
+    y = R_fma.fma(a, b, c)
+    g = torch.autograd.grad(y.square().sum(), [a, b, c])
+    arrays.update({"fma/a": npy(a), "fma/b": npy(b), "fma/c": npy(c), "fma/y": npy(y), "fma/da": npy(g[0]), "fma/db": npy(g[1]), "fma/dc": npy(g[2])})
+    save("modulated_conv2d", arrays, dict(cases=cases))
+
+
+# ---------------------------------------------------------------------------------------------------------------- networks
+
+def state_arrays(module, prefix):
+    return {f"{prefix}/{k}": npy(v) for k, v in module.state_dict().items()}
+
+
+def gen_networks():
+    """whole G / D at 16x16 (channel_base 256, channel_max 32): forward (noise_mode const), and one
+    Gmain + Dmain + R1 gradient set with softplus losses."""
+    for tag, g_arch, d_arch, c_dim, clamp in [("skip_resnet", "skip", "resnet", 0, None), ("orig_orig_c3_clamp", "orig", "orig", 3, 4.0),
+                                               ("resnet_skip", "resnet", "skip", 0, None)]:
+        torch.manual_seed(200)
+        res, cb, cm = 16, 256, 32
+        G = R_net.Generator(z_dim=16, c_dim=c_dim, w_dim=24, img_resolution=res, img_channels=3,
+                            mapping_kwargs=dnnlib.EasyDict(num_layers=2),
+                            synthesis_kwargs=dnnlib.EasyDict(channel_base=cb, channel_max=cm, architecture=g_arch, conv_clamp=clamp))
+        D = R_net.Discriminator(c_dim=c_dim, img_resolution=res, img_channels=3, architecture=d_arch, channel_base=cb, channel_max=cm,
+                                conv_clamp=clamp, mapping_kwargs=dnnlib.EasyDict(num_layers=2), epilogue_kwargs=dnnlib.EasyDict(mbstd_group_size=2))
+        G.train(); D.train()
+        with torch.no_grad():       # non-trivial noise strengths / biases so every term is exercised
+            for name, p in list(G.named_parameters()) + list(D.named_parameters()):
+                if name.endswith("noise_strength"):
+                    p.fill_(0.3)
+                if name.endswith(".bias") and "affine" not in name:
+                    p.copy_(torch.randn_like(p) * 0.1)
+        n = 4
+        z = torch.randn(n, 16)
+        c = torch.nn.functional.one_hot(torch.arange(n) % max(c_dim, 1), max(c_dim, 1)).float()[:, :c_dim]
+        real = torch.randn(n, 3, res, res)
+        arrays = dict(z=npy(z), c=npy(c), real=npy(real))
+        arrays.update(state_arrays(G, "G")); arrays.update(state_arrays(D, "D"))
+        ws = G.mapping(z, c, skip_w_avg_update=True)
+        img = G.synthesis(ws, noise_mode='const', fused_modconv=False)
+        img_fused = G.synthesis(ws, noise_mode='const', fused_modconv=True)
+        logits = D(img, c)
+        arrays.update(ws=npy(ws), img=npy(img), img_fused=npy(img_fused), logits=npy(logits))
+        # training-step gradients (softplus, R1 gamma 0.5), noise_mode const so the draw is reproducible
+        for p in G.parameters(): p.requires_grad_(True)
+        for p in D.parameters(): p.requires_grad_(False)
+        fake = G.synthesis(G.mapping(z, c, skip_w_avg_update=True), noise_mode='const', fused_modconv=False)
+        loss_g = torch.nn.functional.softplus(-D(fake, c)).mean()
+        loss_g.backward()
+        arrays["loss_g"] = npy(loss_g)
+        for name, p in G.named_parameters():
+            arrays[f"gradG/{name}"] = npy(p.grad if p.grad is not None else torch.zeros_like(p))
+        for p in G.parameters(): p.requires_grad_(False)
+        for p in D.parameters(): p.requires_grad_(True)
+        z2 = torch.randn(n, 16)
+        arrays["z2"] = npy(z2)
+        with torch.no_grad():
+            fake = G.synthesis(G.mapping(z2, c, skip_w_avg_update=True), noise_mode='const', fused_modconv=False)
+        real_in = real.clone().requires_grad_(True)
+        real_logits = D(real_in, c)
+        loss_d = torch.nn.functional.softplus(-real_logits).mean() + torch.nn.functional.softplus(D(fake, c)).mean()
+        loss_d.backward(retain_graph=True)
+        arrays["loss_d"] = npy(loss_d)
+        for name, p in D.named_parameters():
+            arrays[f"gradD/{name}"] = npy(p.grad if p.grad is not None else torch.zeros_like(p)); p.grad = None
+        r1 = torch.autograd.grad(real_logits.sum(), real_in, create_graph=True)[0]
+        pen = (r1.square().sum([1, 2, 3]) * (0.5 / 2)).mean()
+        pen.backward()
+        arrays["r1_penalty"] = npy(pen)
+        for name, p in D.named_parameters():
+            arrays[f"gradR1/{name}"] = npy(p.grad if p.grad is not None else torch.zeros_like(p))
+        meta = dict(z_dim=16, c_dim=c_dim, w_dim=24, img_resolution=res, img_channels=3, channel_base=cb, channel_max=cm, mapping_layers=2,
+                    g_architecture=g_arch, d_architecture=d_arch, conv_clamp=clamp, mbstd_group_size=2, r1_gamma=0.5)
+        save(f"networks_{tag}", arrays, meta)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks"]
+    for name in which:
+        globals()["gen_" + name]()
