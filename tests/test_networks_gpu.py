@@ -1,0 +1,113 @@
+"""GPU parity of the StyleGAN2 generator / discriminator modules and of one G+D training step against golden vectors
+captured from the reference (tests/golden/networks_*.npz) -- i.e. against the reference's eager CPU path itself.
+
+Tolerances: fp32 modules (convolutions as six bf16 MFMA passes, fp32 accumulate) 1e-4 of the tensor's max magnitude for
+activations, 1e-3 for first-order parameter gradients and 4e-3 for the R1 (double-backward) gradients, whose tiny values
+come out of long cancelling sums; bf16 modules 6e-2.
+"""
+import pytest
+import torch
+
+import style_big_gan_amd  # noqa: F401
+from golden_util import Golden, max_rel
+from style_big_gan_amd.train_parts import discriminators as PD
+from style_big_gan_amd.train_parts import generators as PG
+
+pytestmark = pytest.mark.gpu
+
+TAGS = ["skip_resnet", "orig_orig_c3_clamp", "resnet_skip"]
+
+
+def build(g, dev, num_fp16_res=0):
+    m = g.meta
+    G = PG.generators["sg2_classic"](
+        z_dim=m["z_dim"], c_dim=m["c_dim"], w_dim=m["w_dim"], img_resolution=m["img_resolution"], img_channels=3,
+        mapping_kwargs=dict(num_layers=m["mapping_layers"]),
+        synthesis_kwargs=dict(channel_base=m["channel_base"], channel_max=m["channel_max"], num_fp16_res=num_fp16_res,
+                              block_kwargs=dict(architecture=m["g_architecture"], conv_clamp=m["conv_clamp"])))
+    D = PD.discriminators["sg2_classic"](
+        c_dim=m["c_dim"], img_resolution=m["img_resolution"], img_channels=3, architecture=m["d_architecture"],
+        channel_base=m["channel_base"], channel_max=m["channel_max"], num_fp16_res=num_fp16_res, conv_clamp=m["conv_clamp"],
+        mapping_kwargs=dict(num_layers=m["mapping_layers"]), epilogue_kwargs=dict(mbstd_group_size=m["mbstd_group_size"]))
+    missing = G.load_state_dict(g.state_dict("G"), strict=True)
+    D.load_state_dict(g.state_dict("D"), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys      # state_dicts interchange with the reference
+    return G.to(dev).train(), D.to(dev).train()
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_forward_fp32(dev, tag):
+    g = Golden("networks_" + tag)
+    G, D = build(g, dev)
+    z, c = g.t("z").to(dev), g.t("c").to(dev)
+    with torch.no_grad():
+        ws = G.mapping(z, c, skip_w_avg_update=True)
+        assert max_rel(ws, g.t("ws")) < 1e-5
+        img = G.synthesis(ws, noise_mode="const")
+        assert max_rel(img, g.t("img")) < 1e-4
+        G.eval()
+        img_eval = G.synthesis(ws, noise_mode="const")       # eval mode = the reference's fused_modconv path
+        assert max_rel(img_eval, g.t("img_fused")) < 1e-4
+        G.train()
+        logits = D(g.t("img").to(dev), c)
+        assert max_rel(logits, g.t("logits")) < 1e-4
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_forward_bf16(dev, tag):
+    g = Golden("networks_" + tag)
+    G, D = build(g, dev, num_fp16_res=8)
+    z, c = g.t("z").to(dev), g.t("c").to(dev)
+    with torch.no_grad():
+        img = G(z, c, noise_mode="const")
+        assert img.dtype == torch.float32
+        assert max_rel(img, g.t("img")) < 6e-2
+        logits = D(g.t("img").to(dev), c)
+        assert max_rel(logits, g.t("logits")) < 6e-2
+
+
+def _check_grads(module, g, prefix, tol):
+    bad = []
+    for name, p in module.named_parameters():
+        ref = g.t(prefix + name)
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        err = max_rel(got, ref)
+        if err >= tol and float(ref.abs().max()) >= 1e-7:
+            bad.append((name, err))
+    assert not bad, f"{prefix}: {bad}"
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_training_step_gradients_fp32(dev, tag):
+    """Gmain / Dmain / R1 gradients w.r.t. every parameter vs the reference's (softplus losses, noise_mode const)."""
+    import torch.nn.functional as F
+    from style_big_gan_amd.torch_utils.ops import conv2d_gradfix
+    g = Golden("networks_" + tag)
+    G, D = build(g, dev)
+    z, z2, c, real = g.t("z").to(dev), g.t("z2").to(dev), g.t("c").to(dev), g.t("real").to(dev)
+    # Gmain
+    G.requires_grad_(True); D.requires_grad_(False)
+    fake = G.synthesis(G.mapping(z, c, skip_w_avg_update=True), noise_mode="const")
+    loss_g = F.softplus(-D(fake, c)).mean()
+    loss_g.backward()
+    assert abs(float(loss_g) - float(g.t("loss_g"))) < 1e-3
+    _check_grads(G, g, "gradG/", 1e-3)
+    # Dmain
+    G.requires_grad_(False); D.requires_grad_(True)
+    with torch.no_grad():
+        fake = G.synthesis(G.mapping(z2, c, skip_w_avg_update=True), noise_mode="const")
+    real_in = real.clone().requires_grad_(True)
+    real_logits = D(real_in, c)
+    loss_d = F.softplus(-real_logits).mean() + F.softplus(D(fake, c)).mean()
+    loss_d.backward(retain_graph=True)
+    assert abs(float(loss_d) - float(g.t("loss_d"))) < 1e-3
+    _check_grads(D, g, "gradD/", 1e-3)
+    for p in D.parameters():
+        p.grad = None
+    # R1 (double backward through every op of D)
+    with conv2d_gradfix.no_weight_gradients():
+        r1 = torch.autograd.grad(real_logits.sum(), real_in, create_graph=True)[0]
+    pen = (r1.square().sum([1, 2, 3]) * (g.meta["r1_gamma"] / 2)).mean()
+    pen.backward()
+    assert abs(float(pen) - float(g.t("r1_penalty"))) < 2e-3 * max(1.0, abs(float(g.t("r1_penalty"))))
+    _check_grads(D, g, "gradR1/", 4e-3)
