@@ -54,7 +54,7 @@ def _pad_channels(t, mult=8):
     cp = (c + mult - 1) // mult * mult
     if cp == c:
         return _cl(t)
-    out = torch.zeros([t.shape[0], cp, t.shape[2], t.shape[3]], dtype=t.dtype, device=t.device).contiguous(memory_format=torch.channels_last)
+    out = torch.empty([t.shape[0], cp, t.shape[2], t.shape[3]], dtype=t.dtype, device=t.device, memory_format=torch.channels_last).zero_()
     out[:, :c] = t
     return out
 
@@ -132,7 +132,7 @@ def _conv_forward(x, w, stride, padding):
     taps = [(i - ph, j - pw, i * kw + j) for i in range(kh) for j in range(kw)]
     passes = _operand_passes(xp, wpk.contiguous())
     multi = len(passes) > 1 or len(taps) > _lib.SBG_MAX_TAPS
-    y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device, memory_format=torch.channels_last)
     first = True
     for xa, wa in passes:
         wa = wa.contiguous()
@@ -174,8 +174,9 @@ def _conv_transpose_forward(x, w, stride, padding, output_padding):
                 continue
             phases.append((a, b, goh, gow, taps))
     multi = len(passes) > 1 or any(len(t) > _lib.SBG_MAX_TAPS for *_, t in phases)
-    alloc = torch.zeros if need_zero else torch.empty
-    y = alloc([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device, memory_format=torch.channels_last)
+    if need_zero:
+        y.zero_()
     first = True
     for xa, wa in passes:
         wa = wa.contiguous()
