@@ -17,6 +17,7 @@
 // rows that are distinct mod 16 -> 16 distinct 16-B slots of the 256-B bank row: conflict-free; the staging writes put 8
 // consecutive rows of one k-group in each 8-lane store group: 128 contiguous bytes, conflict-free.
 #include "sbg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -52,6 +53,54 @@ struct ConvArgs {
 // lane -> (row within a 16-row staging group, k-group): 8 consecutive lanes share a k-group and walk 8 rows.
 static __device__ __forceinline__ int stage_row16(int lane) { return (lane & 7) | ((lane >> 5) << 3); }
 static __device__ __forceinline__ int stage_kgrp(int lane)  { return (lane >> 3) & 3; }
+
+// Epilogue shared by both main loops: lane holds channels c0 + wc + 16 i + 4 fg + {0..3} of pixel p0 + wp + 16 j + fr.
+template <int TC, int TP>
+static __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, float4_t (&acc)[TC][TP], int c0, int p0, int wc, int wp, int fr, int fg)
+{
+#pragma unroll
+    for (int j = 0; j < TP; j++) {
+        const int pix = p0 + wp + 16 * j + fr;
+        if (pix >= p.P) continue;
+        const int ox = pix % p.OW, t = pix / p.OW, oy = t % p.OH, n = t / p.OH;
+        const int64_t yoff = (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
+#pragma unroll
+        for (int i = 0; i < TC; i++) {
+            const int co = c0 + wc + 16 * i + 4 * fg;
+            if (co >= p.Cout) continue;
+            float4_t v = acc[i][j];
+            if (p.oscale) {
+                const float* sc = p.oscale + (int64_t)n * p.Cout + co;
+#pragma unroll
+                for (int e = 0; e < 4; e++) if (co + e < p.Cout) v[e] *= sc[e];
+            }
+            const bool full = (co + 4 <= p.Cout);
+            if (p.ydtype == SBG_F32) {
+                float* dst = (float*)p.y + yoff + co;
+                if (full && ((((uintptr_t)dst) & 15) == 0)) {
+                    float4_t o = v;
+                    if (p.accumulate) { float4_t old = *reinterpret_cast<float4_t*>(dst); o += old; }
+                    *reinterpret_cast<float4_t*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) if (co + e < p.Cout) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
+                }
+            } else {
+                unsigned short* dst = (unsigned short*)p.y + yoff + co;
+                unsigned short h[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) h[e] = (p.ydtype == SBG_BF16) ? f32_to_bf16_bits(v[e]) : f32_to_f16_bits(v[e]);
+                if (full && ((((uintptr_t)dst) & 7) == 0)) {
+                    short4_t o = {(short)h[0], (short)h[1], (short)h[2], (short)h[3]};
+                    *reinterpret_cast<short4_t*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) if (co + e < p.Cout) dst[e] = h[e];
+                }
+            }
+        }
+    }
+}
 
 template <class MF, int BC, int BP, int WGC, int WGP>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
@@ -160,49 +209,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p)
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds channels cbase + 4*fg + {0..3} of pixel (wp + 16 j + fr) ----------------------------
-#pragma unroll
-    for (int j = 0; j < TP; j++) {
-        const int pix = p0 + wp + 16 * j + fr;
-        if (pix >= p.P) continue;
-        const int ox = pix % p.OW, t = pix / p.OW, oy = t % p.OH, n = t / p.OH;
-        const int64_t yoff = (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
-#pragma unroll
-        for (int i = 0; i < TC; i++) {
-            const int co = c0 + wc + 16 * i + 4 * fg;
-            if (co >= p.Cout) continue;
-            float4_t v = acc[i][j];
-            if (p.oscale) {
-                const float* sc = p.oscale + (int64_t)n * p.Cout + co;
-#pragma unroll
-                for (int e = 0; e < 4; e++) if (co + e < p.Cout) v[e] *= sc[e];
-            }
-            const bool full = (co + 4 <= p.Cout);
-            if (p.ydtype == SBG_F32) {
-                float* dst = (float*)p.y + yoff + co;
-                if (full && ((((uintptr_t)dst) & 15) == 0)) {
-                    float4_t o = v;
-                    if (p.accumulate) { float4_t old = *reinterpret_cast<float4_t*>(dst); o += old; }
-                    *reinterpret_cast<float4_t*>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) if (co + e < p.Cout) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
-                }
-            } else {
-                unsigned short* dst = (unsigned short*)p.y + yoff + co;
-                unsigned short h[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) h[e] = (p.ydtype == SBG_BF16) ? f32_to_bf16_bits(v[e]) : f32_to_f16_bits(v[e]);
-                if (full && ((((uintptr_t)dst) & 7) == 0)) {
-                    short4_t o = {(short)h[0], (short)h[1], (short)h[2], (short)h[3]};
-                    *reinterpret_cast<short4_t*>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) if (co + e < p.Cout) dst[e] = h[e];
-                }
-            }
-        }
-    }
+    conv_epilogue<TC, TP>(p, acc, c0, p0, wc, wp, fr, fg);
 }
 
 template <class MF, int BC, int BP, int WGC, int WGP>
@@ -223,10 +230,166 @@ static int launch_conv(ConvArgs& a, hipStream_t stream)
     return SBG_OK;
 }
 
-template <class MF>
-static int dispatch_conv(ConvArgs& a, hipStream_t stream)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA main loop (default).  The register-staged loop above keeps ONE K-step of loads in flight, and under load a
+// global -> LDS round trip costs several K-steps of MFMA time, so waves sit in s_waitcnt (rocprofv3: SQ_WAIT_ANY 58 % of
+// wave cycles, matrix pipe 22 % busy).  Here every stage is filled by `buffer_load_dwordx4 ... lds` (no VGPR staging, no
+// ds_write), NSTAGE = 4 LDS stages deep with 3 K-steps of loads in flight behind a COUNTED s_waitcnt vmcnt(N) and one
+// raw s_barrier per K-step.  Out-of-image taps, ragged rows and channel tails are fetched at an out-of-range buffer
+// offset, which the hardware range check turns into zeros -- padding costs no branches.
+// LDS image per operand and stage: [row][4 slots of 16 B] written lane-linearly (16 rows x 4 slots = 1 KiB per
+// wave-instruction, so a row's 64 B come from one 64-B global segment); the k-group -> slot XOR swizzle
+// slot = g ^ ((-(row >> 2)) & 3) is applied on the SOURCE address and on the fragment read (conflict-free ds_read_b128).
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+#define SBG_OOB_OFFSET 0x80000000u      // >= num_records of every descriptor built below (tensors < 2 GiB)
+
+template <class MF, int BC, int BP, int WGC, int WGP, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
 {
+    static_assert(WGC * WGP == 4, "4 waves per workgroup");
+    constexpr int WC = BC / WGC, WP = BP / WGP;
+    constexpr int TC = WC / 16,  TP = WP / 16;
+    constexpr int DEPTH = NSTAGE - 1;
+    constexpr int A_BYTES = BC * 64, B_BYTES = BP * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int IA = BC / 64, IB = BP / 64;          // DMA instructions per wave per stage (16 rows each)
+    constexpr int PER_STEP = IA + IB;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int ct = bid % p.ctiles, pt = bid / p.ctiles;
+    const int c0 = ct * BC, p0 = pt * BP;
+
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)w_bytes, 0x00020000);
+
+    // ---- per-lane DMA coordinates: lane -> (row = 16-row group base + lane / 4, slot = lane & 3), source k-group = slot ^ swz
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const int src_g = lslot ^ ((-(lrow >> 2)) & 3);
+    int b_iy0[IB], b_ix0[IB]; unsigned b_base[IB];
+#pragma unroll
+    for (int i = 0; i < IB; i++) {
+        const int pix = p0 + (wave * IB + i) * 16 + lrow;
+        const bool ok = pix < p.P;
+        const int pp = ok ? pix : 0;
+        const int ox = pp % p.OW, t = pp / p.OW, oy = t % p.OH, n = t / p.OH;
+        b_iy0[i] = ok ? oy * p.stride : -(1 << 28);           // invalid rows fail every range test below
+        b_ix0[i] = ox * p.stride;
+        b_base[i] = (unsigned)(n * (int)p.xs_n) * 2u;
+    }
+    unsigned a_base[IA];
+#pragma unroll
+    for (int i = 0; i < IA; i++) {
+        const int co = c0 + (wave * IA + i) * 16 + lrow;
+        a_base[i] = (co < p.Cout) ? (unsigned)(co * (int)p.ws_co) * 2u : SBG_OOB_OFFSET;
+    }
+    const int kchunks = (p.Cin + 31) >> 5;
+    const int nsteps = p.ntaps * kchunks;
+
+    auto issue = [&](int step) {
+        const int t = step / kchunks, ck = (step - t * kchunks) * 32 + src_g * 8;
+        const bool kok = ck < p.Cin;
+        unsigned char* st = smem + (step % NSTAGE) * STAGE;
+        const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+        const unsigned wtap = (unsigned)(p.tap_slab[t] * (int)p.ws_slab + ck) * 2u;
+#pragma unroll
+        for (int i = 0; i < IA; i++) {
+            // branch-free select: a masked-off lane would leave stale bytes in LDS instead of zeros
+            const unsigned okm = 0u - (unsigned)(kok & (a_base[i] != SBG_OOB_OFFSET));
+            const unsigned off = ((a_base[i] + wtap) & okm) | (SBG_OOB_OFFSET & ~okm);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + (wave * IA + i) * 1024), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IB; i++) {
+            const int iy = b_iy0[i] + dy, ix = b_ix0[i] + dx;
+            const unsigned okm = 0u - (unsigned)(kok & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW));
+            const unsigned real = b_base[i] + (unsigned)(iy * (int)p.xs_h + ix * (int)p.xs_w + ck) * 2u;
+            const unsigned off = (real & okm) | (SBG_OOB_OFFSET & ~okm);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(st + A_BYTES + (wave * IB + i) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    const int wc = (wave / WGP) * WC, wp = (wave % WGP) * WP;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int rd_slot = fg ^ ((-(fr >> 2)) & 3);
+    float4_t acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; i++)
+#pragma unroll
+        for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < DEPTH; s++) if (s < nsteps) issue(s);
+
+    for (int s = 0; s < nsteps; s++) {
+        // this wave's loads of step s have landed once at most (steps issued after s) * PER_STEP remain outstanding
+        const int ahead = (nsteps - 1 - s < DEPTH - 1) ? nsteps - 1 - s : DEPTH - 1;
+        if (DEPTH >= 3 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PER_STEP) : "memory");
+        else if (ahead >= 1)          asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * PER_STEP) : "memory");
+        else                          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // every wave's part of stage s is in LDS; every wave is done reading stage s - 1
+        if (s + DEPTH < nsteps) issue(s + DEPTH);       // refills the stage read in step s - 1
+        const unsigned char* sa = smem + (s % NSTAGE) * STAGE;
+        const unsigned char* sb = sa + A_BYTES;
+        short8_t fa[TC], fb[TP];
+#pragma unroll
+        for (int i = 0; i < TC; i++) fa[i] = *reinterpret_cast<const short8_t*>(sa + (wc + 16 * i + fr) * 64 + rd_slot * 16);
+#pragma unroll
+        for (int j = 0; j < TP; j++) fb[j] = *reinterpret_cast<const short8_t*>(sb + (wp + 16 * j + fr) * 64 + rd_slot * 16);
+#pragma unroll
+        for (int i = 0; i < TC; i++)
+#pragma unroll
+            for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[i], fb[j], acc[i][j]);
+    }
+    conv_epilogue<TC, TP>(p, acc, c0, p0, wc, wp, fr, fg);
+}
+
+template <class MF, int BC, int BP, int WGC, int WGP, int NSTAGE>
+static int launch_conv_dma(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
+{
+    a.ptiles = (a.P + BP - 1) / BP;
+    a.ctiles = (a.Cout + BC - 1) / BC;
+    const int64_t nblk = (int64_t)a.ptiles * a.ctiles;
+    if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
+    constexpr int lds = NSTAGE * (BC * 64 + BP * 64);
+    auto kern = conv_igemm_dma_kernel<MF, BC, BP, WGC, WGP, NSTAGE>;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
+        attr_set = true;
+    }
+    const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
+    SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
+                      2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
+                      {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, BC * 1000 + BP});
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, x_bytes, w_bytes);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
+
+template <class MF>
+static int dispatch_conv(ConvArgs& a, int64_t x_bytes, int64_t w_bytes, bool allow_dma, hipStream_t stream)
+{
+    // LDS-DMA pipeline whenever both operands fit a 2 GiB buffer descriptor (the out-of-range sentinel sits at 2 GiB)
+    const bool dma = allow_dma && x_bytes < (int64_t)SBG_OOB_OFFSET && w_bytes < (int64_t)SBG_OOB_OFFSET;
     // tile choice: few output channels -> pixel-heavy tile; otherwise 128 x 128.
+    if (dma) {
+        const char* v = getenv("SBG_CONV_TILE");      // experiment switch (tile / pipeline-depth variants)
+        const int variant = v ? atoi(v) : 0;
+        if (a.Cout <= 64) return launch_conv_dma<MF, 64, 256, 1, 4, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
+        if (variant == 1) return launch_conv_dma<MF, 128, 256, 2, 2, 3>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
+        if (variant == 2) return launch_conv_dma<MF, 128, 256, 2, 2, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
+        if (variant == 3) return launch_conv_dma<MF, 128, 128, 2, 2, 3>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
+        return launch_conv_dma<MF, 128, 128, 2, 2, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
+    }
     if (a.Cout <= 64)  return launch_conv<MF, 64, 256, 1, 4>(a, stream);
     return launch_conv<MF, 128, 128, 2, 2>(a, stream);
 }
@@ -261,6 +424,11 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     a.accumulate = q->accumulate;
     a.P = (int)P; a.ptiles = a.ctiles = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (q->xdtype == SBG_BF16) return dispatch_conv<bf16_mfma>(a, s);
-    return dispatch_conv<f16_mfma>(a, s);
+    int maxslab = 0;
+    for (int t = 0; t < q->ntaps; t++) { SBG_CHECK(q->tap_slab[t] >= 0, "conv2d_igemm: negative weight slab"); if (q->tap_slab[t] > maxslab) maxslab = q->tap_slab[t]; }
+    const int64_t x_bytes = 2 * ((int64_t)(q->N - 1) * q->xs_n + (int64_t)(q->IH - 1) * q->xs_h + (int64_t)(q->IW - 1) * q->xs_w + q->Cin);
+    const int64_t w_bytes = 2 * ((int64_t)maxslab * q->ws_slab + (int64_t)(q->Cout - 1) * q->ws_co + q->Cin);
+    const bool allow_dma = getenv("SBG_CONV_NO_DMA") == nullptr && q->xs_n >= 0 && q->xs_h >= 0 && q->xs_w >= 0 && q->ws_slab >= 0 && q->ws_co >= 0;
+    if (q->xdtype == SBG_BF16) return dispatch_conv<bf16_mfma>(a, x_bytes, w_bytes, allow_dma, s);
+    return dispatch_conv<f16_mfma>(a, x_bytes, w_bytes, allow_dma, s);
 }

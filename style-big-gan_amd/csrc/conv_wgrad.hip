@@ -17,6 +17,7 @@
 // every tap, only the gathered b-tiles change.  The pixel axis is split over gridDim.z workgroups that write fp32
 // partial slabs; a second kernel sums the slabs in a fixed order (bitwise reproducible, no float atomics).
 #include "sbg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -196,6 +197,153 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-chunk LDS-DMA kernel: stride 1, |tap offset| <= 1, PW % 32 == 0 (every 3x3 / 1x1 pad-same layer from 32x32 up).
+// A K-chunk is 32 consecutive pixels of ONE image row; the b operand of all nine taps is the 3-row x 34-pixel halo of that
+// chunk, staged ONCE (15 KB instead of nine gathered 4 KB tiles) next to the 4 KB a-tile.  Stages are filled by
+// `buffer_load_dwordx4 ... lds` (out-of-image pixels -> out-of-range offset -> zeros), three stages deep with two chunks of
+// loads in flight behind a counted s_waitcnt vmcnt and one raw s_barrier per chunk (the register-staged kernel above keeps
+// one chunk in flight and spends most of its wave cycles in s_waitcnt).
+// LDS rows are 128 B (64 channels) and cannot be padded under LDS-DMA, so the 16-B chunk pairs of row R are XOR-swizzled by
+// (R >> 1) & 3 on the source side and in the transposing reads: any 8 consecutive rows then cover 8 distinct 32-B bank slots.
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+#define SBG_OOB_OFFSET 0x80000000u
+
+template <class MF>
+__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsigned a_bytes, unsigned b_bytes)
+{
+    constexpr int BC = 64, NT = 9, NSTAGE = 3, DEPTH = 2;
+    constexpr int PROW = 40;                                   // patch row pitch in pixels (34 used)
+    constexpr int A_BYTES = 32 * 128, P_BYTES = 3 * PROW * 128, STAGE = A_BYTES + P_BYTES + 1024;   // + one spare piece
+    constexpr int PIECES = 5;                                  // DMA instructions per wave per stage (20 pieces of 1 KiB)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ca0 = blockIdx.x * BC, cb0 = blockIdx.y * BC, split = blockIdx.z;
+    const int chunk_begin = split * p.chunks_per_split;
+    int chunk_end = chunk_begin + p.chunks_per_split;
+    if (chunk_end > p.nchunks) chunk_end = p.nchunks;
+    const int nloc = chunk_end - chunk_begin;
+    const int xblocks = p.PW >> 5;
+
+    __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, (int)b_bytes, 0x00020000);
+
+    // ---- DMA lane coordinates: piece = 8 rows x 8 chunks of 16 B; lane -> (row = lane / 8, LDS chunk = lane % 8)
+    const int drow = lane >> 3, dchunk = lane & 7;
+    auto src_chunk = [&](int R) { return (((dchunk >> 1) ^ ((R >> 1) & 3)) << 1) | (dchunk & 1); };   // swizzled source chunk for LDS row R
+
+    auto issue = [&](int loc) {
+        const int c = chunk_begin + loc;
+        const int xb = c % xblocks, rowid = c / xblocks;
+        const int py = rowid % p.PH, n = rowid / p.PH;
+        const int px0 = xb << 5;
+        unsigned char* st = smem + (loc % NSTAGE) * STAGE;
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) {
+            const int piece = wave + 4 * i;                    // 0..19, wave-uniform
+            if (piece < 4) {                                   // a-tile rows 8*piece ..
+                const int R = piece * 8 + drow;
+                const int ch = ca0 + src_chunk(R) * 8;
+                const unsigned okm = 0u - (unsigned)(ch < p.Ca);
+                const unsigned real = (unsigned)(n * (int)p.as_n + py * (int)p.as_h + (px0 + R) * (int)p.as_w + ch) * 2u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_void_ptr)(st + piece * 1024), 16, (real & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
+            } else {
+                const int q = piece - 4;                       // 0..15; 15 = spare
+                const int r = q / 5, jb = q - r * 5;
+                const int R = r * PROW + jb * 8 + drow;        // LDS row inside the patch
+                const int by = py + r - 1, bx = px0 - 1 + jb * 8 + drow;
+                const int ch = cb0 + src_chunk(R) * 8;
+                const unsigned okm = 0u - (unsigned)((q < 15) & ((unsigned)by < (unsigned)p.BH) & ((unsigned)bx < (unsigned)p.BW) & (ch < p.Cb));
+                const unsigned real = (unsigned)(n * (int)p.bs_n + by * (int)p.bs_h + bx * (int)p.bs_w + ch) * 2u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_void_ptr)(st + A_BYTES + q * 1024), 16, (real & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
+            }
+        }
+    };
+
+    const int wa = (wave >> 1) * 32, wb = (wave & 1) * 32;
+    const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
+    float4_t acc[NT][2][2];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[t][i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    // Per-lane LDS byte offsets of the transposing reads, computed once.  The tap order is fixed (t = 3*(dy+1) + (dx+1)), so
+    // inside the chunk loop every read is `per-lane base (one of 3 dx variants) + compile-time constant`.
+    // For LDS row R = 40*(1+dy) + (1+dx) + 4g + q (and R + 16) the swizzle term (R >> 1) & 3 depends on dx only.
+    auto frag_off = [&](int Rrel, int col) {
+        const int chunk = (col >> 3) + (fp >> 1);
+        const int sw = (((chunk >> 1) ^ ((Rrel >> 1) & 3)) << 1) | (chunk & 1);
+        return Rrel * 128 + sw * 16 + (fp & 1) * 8;
+    };
+    int offA[2], offB[3][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) offA[i] = frag_off(4 * fg + fq, wa + 16 * i);
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) offB[d][j] = frag_off(d + 4 * fg + fq, wb + 16 * j);
+    auto read_frag = [&](const unsigned char* base, int off) -> short8_t {
+        short4_t lo = lds_tr_read(base + off), hi = lds_tr_read(base + off + 16 * 128);
+        return short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+#pragma unroll
+    for (int s = 0; s < DEPTH; s++) if (s < nloc) issue(s);
+    for (int s = 0; s < nloc; s++) {
+        if (nloc - 1 - s >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        else                   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + DEPTH < nloc) issue(s + DEPTH);
+        const unsigned char* sA = smem + (s % NSTAGE) * STAGE;
+        const unsigned char* sP = sA + A_BYTES;
+        short8_t fa[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) fa[i] = read_frag(sA, offA[i]);
+#pragma unroll
+        for (int dyi = 0; dyi < 3; dyi++)
+#pragma unroll
+            for (int dxi = 0; dxi < 3; dxi++) {
+                short8_t fb[2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) fb[j] = read_frag(sP + dyi * PROW * 128, offB[dxi][j]);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[dyi * 3 + dxi][i][j] = Mfma<MF>::run(fa[i], fb[j], acc[dyi * 3 + dxi][i][j]);
+            }
+    }
+
+    const bool direct = (p.nsplit == 1);
+    float* dst_base = direct ? p.out : p.ws + (int64_t)split * p.ntaps_total * p.Ca * p.Cb;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (t >= p.ntaps) continue;
+        float* slab = dst_base + (int64_t)(p.tap0 + t) * p.Ca * p.Cb;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int cb = cb0 + wb + 16 * j + fi;
+                if (cb >= p.Cb) continue;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int ca = ca0 + wa + 16 * i + 4 * fg + e;
+                    if (ca >= p.Ca) continue;
+                    float* d = slab + (int64_t)ca * p.Cb + cb;
+                    const float v = acc[t][i][j][e];
+                    *d = (direct && p.accumulate) ? *d + v : v;
+                }
+            }
+    }
+}
+
 // out[i] (+)= sum_s ws[s][i], fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* out, int64_t n, int nsplit, int accumulate)
 {
@@ -222,6 +370,20 @@ static void plan_split(WgradArgs& a, int bca, int bcb)
 }
 
 static bool use_big_tile(int ntaps) { return ntaps == 1; }
+
+static bool rows_kernel_ok(const sbg_wgrad_params* q, const WgradArgs& a)
+{
+    if (getenv("SBG_WGRAD_NO_DMA")) return false;
+    if (q->stride != 1 || (q->PW % 32) != 0 || q->ntaps > 9 || q->ntaps < 2) return false;
+    if (q->PH != q->BH || q->PW != q->BW) return false;
+    if (q->ntaps != 9) return false;
+    for (int t = 0; t < 9; t++)          // the kernel hard-codes the row-major 3x3 tap order
+        if (q->tap_dy[t] != t / 3 - 1 || q->tap_dx[t] != t % 3 - 1) return false;
+    if (q->as_n < 0 || q->as_h < 0 || q->as_w < 0 || q->bs_n < 0 || q->bs_h < 0 || q->bs_w < 0) return false;
+    const int64_t ab = 2 * ((int64_t)(q->N - 1) * q->as_n + (int64_t)(q->PH - 1) * q->as_h + (int64_t)(q->PW - 1) * q->as_w + q->Ca);
+    const int64_t bb = 2 * ((int64_t)(q->N - 1) * q->bs_n + (int64_t)(q->BH - 1) * q->bs_h + (int64_t)(q->BW - 1) * q->bs_w + q->Cb);
+    return ab < (int64_t)SBG_OOB_OFFSET && bb < (int64_t)SBG_OOB_OFFSET && a.P > 0;
+}
 
 static int fill_args(const sbg_wgrad_params* q, WgradArgs& a)
 {
@@ -287,7 +449,17 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
     }
     SBG_CHECK(a.nsplit == 1 || a.ws != nullptr, "conv2d_wgrad: workspace required (%d pixel splits)", a.nsplit);
     const bool bf = (q->dtype == SBG_BF16);
-    if (use_big_tile(a.ntaps)) {
+    if (rows_kernel_ok(q, a)) {
+        const unsigned ab = (unsigned)(2 * ((int64_t)(q->N - 1) * q->as_n + (int64_t)(q->PH - 1) * q->as_h + (int64_t)(q->PW - 1) * q->as_w + q->Ca));
+        const unsigned bb = (unsigned)(2 * ((int64_t)(q->N - 1) * q->bs_n + (int64_t)(q->BH - 1) * q->bs_h + (int64_t)(q->BW - 1) * q->bs_w + q->Cb));
+        constexpr int lds = 3 * (32 * 128 + 3 * 40 * 128 + 1024);
+        SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
+                          2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
+                          {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, 64064});
+        if (bf) hipLaunchKernelGGL(conv_wgrad_rows_kernel<bf16_mfma>, dim3(a.atiles, a.btiles, a.nsplit), dim3(256), lds, s, a, ab, bb);
+        else    hipLaunchKernelGGL(conv_wgrad_rows_kernel<f16_mfma>, dim3(a.atiles, a.btiles, a.nsplit), dim3(256), lds, s, a, ab, bb);
+        SBG_HIP_LAUNCH_CHECK();
+    } else if (use_big_tile(a.ntaps)) {
         rc = bf ? launch_wgrad<bf16_mfma, 128, 128, 1>(a, s) : launch_wgrad<f16_mfma, 128, 128, 1>(a, s);
         if (rc != SBG_OK) return rc;
     } else {

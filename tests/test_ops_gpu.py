@@ -242,3 +242,22 @@ def test_fma(dev):
     gr = torch.autograd.grad(yr.square().sum(), [a, b, c]); gg = torch.autograd.grad(yg.square().sum(), [ag, bg, cg])
     for u, v in zip(gg, gr):
         check(u, v, 1e-5)
+
+
+def test_conv3x3_halo_kernel_matches_gather_kernel_and_oracle(dev):
+    """shapes that take the halo-staged kernel (W % 32 == 0 and H % 8 == 0, or 16-multiples), incl. ragged channel counts"""
+    for dtype in [torch.bfloat16, torch.float32]:
+        for (n, cin, cout, h, w, k) in [(2, 32, 128, 8, 32, 3), (1, 40, 72, 16, 32, 3), (2, 136, 200, 16, 16, 3), (3, 64, 64, 32, 64, 3),
+                                        (2, 16, 24, 16, 16, 1), (1, 8, 130, 8, 64, 3)]:
+            _conv_case(dev, dtype, n, cin, cout, h, w, k, 1, k // 2, False)
+    torch.manual_seed(8)
+    x = torch.randn(2, 64, 16, 32, device=dev, dtype=torch.bfloat16)
+    w = (torch.randn(96, 64, 3, 3, device=dev) / 24).to(torch.bfloat16)
+    conv2d_gradfix.use_halo_kernel = True
+    y_halo = conv2d_gradfix.conv2d(x, w, padding=1)
+    conv2d_gradfix.use_halo_kernel = False
+    try:
+        y_gather = conv2d_gradfix.conv2d(x, w, padding=1)
+    finally:
+        conv2d_gradfix.use_halo_kernel = True
+    assert torch.equal(y_halo, y_gather) or rel_err(y_halo, y_gather) < 1e-2    # same math, different summation order
