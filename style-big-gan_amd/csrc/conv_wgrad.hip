@@ -211,13 +211,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 #define SBG_OOB_OFFSET 0x80000000u
 
-template <class MF>
+template <class MF, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsigned a_bytes, unsigned b_bytes)
 {
+    // S = stride between the coarse (a) and fine (b) grids: b pixel = S * a pixel + tap, taps = (dy0 + i, dx0 + j), i, j in 0..2
     constexpr int BC = 64, NT = 9, NSTAGE = 3, DEPTH = 2;
-    constexpr int PROW = 40;                                   // patch row pitch in pixels (34 used)
-    constexpr int A_BYTES = 32 * 128, P_BYTES = 3 * PROW * 128, STAGE = A_BYTES + P_BYTES + 1024;   // + one spare piece
-    constexpr int PIECES = 5;                                  // DMA instructions per wave per stage (20 pieces of 1 KiB)
+    constexpr int PCOLS = S * 31 + 3;                          // b columns needed by a 32-pixel chunk
+    constexpr int PPR = (PCOLS + 7) / 8;                       // 8-pixel DMA pieces per patch row
+    constexpr int PROW = PPR * 8;                              // patch row pitch in pixels
+    constexpr int NPIECE = ((4 + 3 * PPR + 3) / 4) * 4;        // a-tile (4) + patch pieces, padded to a multiple of 4 with spares
+    constexpr int PIECES = NPIECE / 4;                         // DMA instructions per wave per stage
+    constexpr int A_BYTES = 32 * 128, STAGE = NPIECE * 1024;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
     if (chunk_end > p.nchunks) chunk_end = p.nchunks;
     const int nloc = chunk_end - chunk_begin;
     const int xblocks = p.PW >> 5;
+    const int dy0 = p.tap_dy[0], dx0 = p.tap_dx[0];
 
     __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)a_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, (int)b_bytes, 0x00020000);
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         unsigned char* st = smem + (loc % NSTAGE) * STAGE;
 #pragma unroll
         for (int i = 0; i < PIECES; i++) {
-            const int piece = wave + 4 * i;                    // 0..19, wave-uniform
+            const int piece = wave + 4 * i;                    // wave-uniform
             if (piece < 4) {                                   // a-tile rows 8*piece ..
                 const int R = piece * 8 + drow;
                 const int ch = ca0 + src_chunk(R) * 8;
@@ -252,12 +257,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
                 const unsigned real = (unsigned)(n * (int)p.as_n + py * (int)p.as_h + (px0 + R) * (int)p.as_w + ch) * 2u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_void_ptr)(st + piece * 1024), 16, (real & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
             } else {
-                const int q = piece - 4;                       // 0..15; 15 = spare
-                const int r = q / 5, jb = q - r * 5;
+                const int q = piece - 4;                       // patch piece; q >= 3 * PPR are spares (zeros)
+                const int r = q / PPR, jb = q - r * PPR;
                 const int R = r * PROW + jb * 8 + drow;        // LDS row inside the patch
-                const int by = py + r - 1, bx = px0 - 1 + jb * 8 + drow;
+                const int by = S * py + dy0 + r, bx = S * px0 + dx0 + jb * 8 + drow;
                 const int ch = cb0 + src_chunk(R) * 8;
-                const unsigned okm = 0u - (unsigned)((q < 15) & ((unsigned)by < (unsigned)p.BH) & ((unsigned)bx < (unsigned)p.BW) & (ch < p.Cb));
+                const unsigned okm = 0u - (unsigned)((q < 3 * PPR) & ((unsigned)by < (unsigned)p.BH) & ((unsigned)bx < (unsigned)p.BW) & (ch < p.Cb));
                 const unsigned real = (unsigned)(n * (int)p.bs_n + by * (int)p.bs_h + bx * (int)p.bs_w + ch) * 2u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_void_ptr)(st + A_BYTES + q * 1024), 16, (real & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
             }
@@ -274,9 +279,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
 #pragma unroll
             for (int j = 0; j < 2; j++) acc[t][i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
-    // Per-lane LDS byte offsets of the transposing reads, computed once.  The tap order is fixed (t = 3*(dy+1) + (dx+1)), so
-    // inside the chunk loop every read is `per-lane base (one of 3 dx variants) + compile-time constant`.
-    // For LDS row R = 40*(1+dy) + (1+dx) + 4g + q (and R + 16) the swizzle term (R >> 1) & 3 depends on dx only.
+    // Per-lane LDS byte offsets of the transposing reads, computed once.  The tap order is fixed (t = 3 i + j), so inside the
+    // chunk loop every read is `per-lane base (one of 3 column-tap variants) + compile-time constant`.
+    // For patch row R = PROW*i + j + S*(4g + q) (and R + 16 S) the swizzle term (R >> 1) & 3 depends on j only (PROW % 8 == 0).
     auto frag_off = [&](int Rrel, int col) {
         const int chunk = (col >> 3) + (fp >> 1);
         const int sw = (((chunk >> 1) ^ ((Rrel >> 1) & 3)) << 1) | (chunk & 1);
@@ -288,9 +293,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
 #pragma unroll
     for (int d = 0; d < 3; d++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) offB[d][j] = frag_off(d + 4 * fg + fq, wb + 16 * j);
-    auto read_frag = [&](const unsigned char* base, int off) -> short8_t {
-        short4_t lo = lds_tr_read(base + off), hi = lds_tr_read(base + off + 16 * 128);
+        for (int j = 0; j < 2; j++) offB[d][j] = frag_off(d + S * (4 * fg + fq), wb + 16 * j);
+    auto read_frag = [&](const unsigned char* base, int off, int hi_off) -> short8_t {
+        short4_t lo = lds_tr_read(base + off), hi = lds_tr_read(base + off + hi_off);
         return short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
@@ -305,14 +310,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         const unsigned char* sP = sA + A_BYTES;
         short8_t fa[2];
 #pragma unroll
-        for (int i = 0; i < 2; i++) fa[i] = read_frag(sA, offA[i]);
+        for (int i = 0; i < 2; i++) fa[i] = read_frag(sA, offA[i], 16 * 128);
 #pragma unroll
         for (int dyi = 0; dyi < 3; dyi++)
 #pragma unroll
             for (int dxi = 0; dxi < 3; dxi++) {
                 short8_t fb[2];
 #pragma unroll
-                for (int j = 0; j < 2; j++) fb[j] = read_frag(sP + dyi * PROW * 128, offB[dxi][j]);
+                for (int j = 0; j < 2; j++) fb[j] = read_frag(sP + dyi * PROW * 128, offB[dxi][j], S * 16 * 128);
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -374,11 +379,9 @@ static bool use_big_tile(int ntaps) { return ntaps == 1; }
 static bool rows_kernel_ok(const sbg_wgrad_params* q, const WgradArgs& a)
 {
     if (getenv("SBG_WGRAD_NO_DMA")) return false;
-    if (q->stride != 1 || (q->PW % 32) != 0 || q->ntaps > 9 || q->ntaps < 2) return false;
-    if (q->PH != q->BH || q->PW != q->BW) return false;
-    if (q->ntaps != 9) return false;
-    for (int t = 0; t < 9; t++)          // the kernel hard-codes the row-major 3x3 tap order
-        if (q->tap_dy[t] != t / 3 - 1 || q->tap_dx[t] != t % 3 - 1) return false;
+    if ((q->stride != 1 && q->stride != 2) || (q->PW % 32) != 0 || q->ntaps != 9) return false;
+    for (int t = 0; t < 9; t++)          // the kernel hard-codes a row-major 3x3 tap window starting at (dy[0], dx[0])
+        if (q->tap_dy[t] != q->tap_dy[0] + t / 3 || q->tap_dx[t] != q->tap_dx[0] + t % 3) return false;
     if (q->as_n < 0 || q->as_h < 0 || q->as_w < 0 || q->bs_n < 0 || q->bs_h < 0 || q->bs_w < 0) return false;
     const int64_t ab = 2 * ((int64_t)(q->N - 1) * q->as_n + (int64_t)(q->PH - 1) * q->as_h + (int64_t)(q->PW - 1) * q->as_w + q->Ca);
     const int64_t bb = 2 * ((int64_t)(q->N - 1) * q->bs_n + (int64_t)(q->BH - 1) * q->bs_h + (int64_t)(q->BW - 1) * q->bs_w + q->Cb);
@@ -452,12 +455,24 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
     if (rows_kernel_ok(q, a)) {
         const unsigned ab = (unsigned)(2 * ((int64_t)(q->N - 1) * q->as_n + (int64_t)(q->PH - 1) * q->as_h + (int64_t)(q->PW - 1) * q->as_w + q->Ca));
         const unsigned bb = (unsigned)(2 * ((int64_t)(q->N - 1) * q->bs_n + (int64_t)(q->BH - 1) * q->bs_h + (int64_t)(q->BW - 1) * q->bs_w + q->Cb));
-        constexpr int lds = 3 * (32 * 128 + 3 * 40 * 128 + 1024);
+        const int lds = (q->stride == 1) ? 3 * 20 * 1024 : 3 * 32 * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 1024);
+            attr_set = true;
+        }
         SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                           2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
                           {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, 64064});
-        if (bf) hipLaunchKernelGGL(conv_wgrad_rows_kernel<bf16_mfma>, dim3(a.atiles, a.btiles, a.nsplit), dim3(256), lds, s, a, ab, bb);
-        else    hipLaunchKernelGGL(conv_wgrad_rows_kernel<f16_mfma>, dim3(a.atiles, a.btiles, a.nsplit), dim3(256), lds, s, a, ab, bb);
+        const dim3 grid(a.atiles, a.btiles, a.nsplit);
+        if (q->stride == 1) {
+            if (bf) hipLaunchKernelGGL((conv_wgrad_rows_kernel<bf16_mfma, 1>), grid, dim3(256), lds, s, a, ab, bb);
+            else    hipLaunchKernelGGL((conv_wgrad_rows_kernel<f16_mfma, 1>), grid, dim3(256), lds, s, a, ab, bb);
+        } else {
+            if (bf) hipLaunchKernelGGL((conv_wgrad_rows_kernel<bf16_mfma, 2>), grid, dim3(256), lds, s, a, ab, bb);
+            else    hipLaunchKernelGGL((conv_wgrad_rows_kernel<f16_mfma, 2>), grid, dim3(256), lds, s, a, ab, bb);
+        }
         SBG_HIP_LAUNCH_CHECK();
     } else if (use_big_tile(a.ntaps)) {
         rc = bf ? launch_wgrad<bf16_mfma, 128, 128, 1>(a, s) : launch_wgrad<f16_mfma, 128, 128, 1>(a, s);

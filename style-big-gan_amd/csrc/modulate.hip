@@ -196,8 +196,13 @@ extern "C" int sbg_scale_nc(const void* x, const float* a, const float* z, void*
 extern "C" int sbg_dot_hw_splits(int layout, int N, int C, int64_t HW)
 {
     if (!dot_fast(layout, C)) return 1;
-    int64_t s = (HW + DOT_PIX_PER_SPLIT - 1) / DOT_PIX_PER_SPLIT;
-    return (int)(s < 1 ? 1 : s);
+    // enough (sample, split) workgroups to fill the chip (~4 per CU), at least 64 pixels of work each
+    int64_t want = (1024 + N - 1) / (N > 0 ? N : 1);
+    const int64_t most = (HW + 63) / 64;
+    if (want > most) want = most;
+    if (want < 1) want = 1;
+    const int64_t pps = (HW + want - 1) / want;
+    return (int)((HW + pps - 1) / pps);
 }
 
 extern "C" int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layout,
@@ -211,7 +216,7 @@ extern "C" int sbg_dot_hw(const void* u, const void* v, float* partial, int dtyp
     DotArgs p; p.u = u; p.v = v; p.partial = partial; p.N = N; p.C = C; p.HW = HW;
     const bool fast = dot_fast(layout, C) && sbg_aligned16(u) && (!v || sbg_aligned16(v));
     p.nsplit = dot_fast(layout, C) ? sbg_dot_hw_splits(layout, N, C, HW) : 1;
-    p.pix_per_split = DOT_PIX_PER_SPLIT;
+    p.pix_per_split = (HW + p.nsplit - 1) / p.nsplit;
     hipStream_t s = (hipStream_t)stream;
     if (!fast && p.nsplit > 1) {
         // unaligned view of a channel-minor tensor: the generic kernel writes split 0 only; zero the others

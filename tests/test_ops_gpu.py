@@ -211,6 +211,11 @@ def test_conv2d_large_k_and_many_pixels(dev):
     _conv_case(dev, torch.bfloat16, 4, 64, 64, 64, 64, 3, 1, 1, False)
     _conv_case(dev, torch.float32, 2, 32, 32, 40, 40, 3, 1, 1, False)
     _conv_case(dev, torch.bfloat16, 2, 128, 128, 32, 32, 1, 1, 0, False)
+    # row-chunk LDS-DMA weight-gradient kernel: stride 1 and stride 2 (forward strided conv and transposed conv), ragged channels
+    _conv_case(dev, torch.bfloat16, 2, 72, 40, 32, 64, 3, 1, 1, False)
+    _conv_case(dev, torch.bfloat16, 2, 40, 72, 65, 65, 3, 2, 0, False)     # -> 32 x 32
+    _conv_case(dev, torch.bfloat16, 2, 72, 40, 32, 32, 3, 2, 0, True)      # -> 65 x 65
+    _conv_case(dev, torch.float32, 1, 16, 24, 65, 129, 3, 2, 0, False)     # -> 32 x 64
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
