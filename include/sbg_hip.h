@@ -166,6 +166,10 @@ int     sbg_conv2d_wgrad(const sbg_wgrad_params* p, sbg_stream_t stream);
  * layout: 0 = planar [N][C][HW], 1 = channel-minor [N][HW][C]; x and y dense in that layout. */
 int sbg_scale_nc(const void* x, const float* a, const float* z, void* y, int dtype, int layout,
                  int N, int C, int64_t HW, int64_t z_stride_n, sbg_stream_t stream);
+/* Same with a per-sample, per-channel addend (the normalise-and-modulate step of biggan/layers.py `ccbn` / `bn` / `fused_bn`
+ * :173-187,306-325 once the statistics are known):  y[n,c,p] = x[n,c,p] * a[n*C + c] + b[n*C + c]. */
+int sbg_scale_shift_nc(const void* x, const float* a, const float* b, void* y, int dtype, int layout,
+                       int N, int C, int64_t HW, sbg_stream_t stream);
 
 /* Per-sample, per-channel dot product over pixels (the gradient of the scaling above w.r.t. `a`, and -- with
  * v == NULL -- the bias gradient `dx.sum([2, 3])` of bias_act.py:172-173):
@@ -175,6 +179,27 @@ int sbg_dot_hw_splits(int layout, int N, int C, int64_t HW);
 int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layout,
                int N, int C, int64_t HW, sbg_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Spectral norm, one power iteration with one singular vector (biggan/layers.py `power_iteration` :28-50, `SN.W_` :87-99):
+ *   v = normalize(u W), u' = normalize(v W^T), sigma = (v W^T) . u'        W: fp32 [rows, cols] row-major, u: fp32 [rows]
+ * Writes v [cols], u_new [rows] (both normalised with F.normalize's max(norm, eps)) and sigma [1]; `workspace` holds
+ * sbg_sn_workspace(rows, cols) bytes.  The caller decides whether u_new replaces the stored u (training) -- nothing is
+ * updated in place.  d sigma / d W = outer(u_new, v) is applied by the host autograd Function. */
+int64_t sbg_sn_workspace(int rows, int cols);
+int sbg_sn_power_iteration(const float* W, const float* u, float* v, float* u_new, float* sigma, void* workspace,
+                           int rows, int cols, float eps, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Non-local self-attention core (biggan/layers.py `Attention.forward` :162-166): for every sample n
+ *   out[n, q, :] = softmax_m( theta[n, q, :] . phi[n, m, :] ) @ g[n, m, :]
+ * theta: fp32 [N, Q, D], phi: fp32 [N, M, D], g: fp32 [N, M, DV], out: fp32 [N, Q, DV], all row-major dense.
+ * Exact-fp32 matrix-core kernel (v_mfma_f32_16x16x4_f32); the [Q, M] attention map never touches HBM.
+ * Supported: Q % 16 == 0, M % 16 == 0, M <= 256, D % 4 == 0, DV % 16 == 0 (sbg_attention_supported). */
+int sbg_attention_supported(int Q, int M, int D, int DV);
+int sbg_attention_fwd(const float* theta, const float* phi, const float* g, float* out, int N, int Q, int M, int D, int DV,
+                      sbg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * In-process launch timing (measurement only; bench.py's roofline figures come from here).
  * While enabled, every kernel launch of this library is bracketed by two hipEvents recorded on the launch stream
@@ -183,7 +208,7 @@ int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layo
  * (or the number pending when out == NULL). */
 enum sbg_kernel_kind {
     SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
-    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_CONV3X3_HALO = 8
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_CONV3X3_HALO = 8, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10
 };
 typedef struct sbg_prof_record {
     int    kind;            /* enum sbg_kernel_kind */

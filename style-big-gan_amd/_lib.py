@@ -87,7 +87,7 @@ class ProfRecord(ctypes.Structure):
                 ("ms", ctypes.c_float), ("pad", ctypes.c_int)]
 
 
-KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 8: "conv3x3_halo"}
+KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 8: "conv3x3_halo", 9: "sn_power", 10: "attention"}
 
 _lib = None
 _lock = threading.Lock()
@@ -106,6 +106,11 @@ SYMBOLS = [
     ("sbg_conv2d_wgrad_workspace", _c.c_int64, [_c.POINTER(WgradParams)]),
     ("sbg_conv2d_wgrad", _c.c_int, [_c.POINTER(WgradParams), _c.c_void_p]),
     ("sbg_scale_nc", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_void_p]),
+    ("sbg_scale_shift_nc", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
+    ("sbg_sn_workspace", _c.c_int64, [_c.c_int, _c.c_int]),
+    ("sbg_sn_power_iteration", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int, _c.c_int, _c.c_float, _c.c_void_p]),
+    ("sbg_attention_supported", _c.c_int, [_c.c_int] * 4),
+    ("sbg_attention_fwd", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_dot_hw_splits", _c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64]),
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_prof_enable", _c.c_int, [_c.c_int]),

@@ -1,0 +1,372 @@
+"""BigGAN building blocks over the HIP op layer.
+
+Mirror of the reference's ``biggan/layers.py`` API used by the registered models: ``SN`` / ``SNConv2d`` / ``SNLinear`` /
+``SNEmbedding`` (:60-138), ``Attention`` (:144-169), ``ccbn`` (:278-330), ``bn`` (:333-366), ``GBlock`` (:375-409),
+``DBlock`` (:412-457), ``identity`` (:54) with the same constructor arguments, buffer names (``u0``, ``sv0``, ``stored_mean``,
+``stored_var``) and forward semantics, so state_dicts interchange.  Underneath:
+
+* spectral norm: one fused power-iteration kernel pair (``sbg_sn_power_iteration``) gives v, u', sigma; the gradient
+  d sigma / d W = outer(u', v) is an autograd Function, the weight is divided by sigma as in the reference (:99);
+* convolutions are the implicit-GEMM MFMA kernels (``conv2d_gradfix``), ReLU is ``bias_act``, nearest up-sampling and 2x2
+  average pooling are ``upfirdn2d`` with 2x2 box filters;
+* attention: ``softmax(theta^T phi) g`` is one exact-fp32 matrix-core kernel (``sbg_attention_fwd``) -- the [HW, HW/4] map
+  never reaches HBM; its backward re-derives the map with library batched GEMMs (differentiable again, so R1 works);
+* batch norm: statistics by the ``sbg_dot_hw`` reductions (sum, sum of squares), normalise + class-conditional gain/bias in
+  one ``sbg_scale_shift_nc`` pass; ``cross_replica=True`` all-reduces [sum, sum^2, count] over RCCL (differentiable) and
+  uses the reference's synchronized formula (sync_batchnorm/batchnorm.py:147-158) -- the reference's DataParallel-only
+  mechanism is not reproduced.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import Parameter as P
+
+from .. import _lib
+from ..torch_utils.ops import bias_act, conv2d_gradfix, modulate, upfirdn2d
+
+
+class identity(nn.Module):
+    def forward(self, input):
+        return input
+
+
+class ReLU(nn.Module):
+    """out-of-place ReLU on the fused bias_act kernel (gain 1)"""
+
+    def forward(self, x):
+        if x.device.type != "cuda":
+            return F.relu(x)
+        return bias_act.bias_act(x, act="relu", gain=1)
+
+
+def nearest_upsample2x(x):
+    """F.interpolate(scale_factor=2) (nearest) as a zero-insert + 2x2 box FIR"""
+    f = torch.ones([2, 2], dtype=torch.float32, device=x.device)
+    return upfirdn2d.upfirdn2d(x, f, up=2, padding=[1, 0, 1, 0])
+
+
+def avg_pool2x(x):
+    """nn.AvgPool2d(2) as a 2x2 box FIR with decimation"""
+    f = torch.full([2, 2], 0.25, dtype=torch.float32, device=x.device)
+    return upfirdn2d.upfirdn2d(x, f, down=2)
+
+
+# ---------------------------------------------------------------------------------------------------------------- spectral norm
+
+class _SpectralSigma(torch.autograd.Function):
+    """(W_mat [rows, cols], u [1, rows]) -> (sigma, u_new, v) by one power iteration; d sigma / d W = outer(u_new, v)"""
+
+    @staticmethod
+    def forward(ctx, W_mat, u, eps):
+        lib = _lib.load()
+        _lib.require_cuda(W_mat, "spectral norm")
+        Wc = W_mat.detach().to(torch.float32).contiguous()
+        rows, cols = Wc.shape
+        uc = u.detach().reshape(rows).to(torch.float32).contiguous()
+        v = torch.empty([cols], dtype=torch.float32, device=Wc.device)
+        u_new = torch.empty([rows], dtype=torch.float32, device=Wc.device)
+        sigma = torch.empty([1], dtype=torch.float32, device=Wc.device)
+        ws = torch.empty([lib.sbg_sn_workspace(rows, cols) // 4], dtype=torch.float32, device=Wc.device)
+        _lib.check(lib.sbg_sn_power_iteration(_lib.ptr(Wc), _lib.ptr(uc), _lib.ptr(v), _lib.ptr(u_new), _lib.ptr(sigma), _lib.ptr(ws),
+                                              rows, cols, float(eps), _lib.stream_ptr(Wc.device)), "sbg_sn_power_iteration")
+        ctx.save_for_backward(u_new, v)
+        ctx.mark_non_differentiable(u_new, v)
+        return sigma.reshape([]), u_new.reshape(1, rows), v.reshape(1, cols)
+
+    @staticmethod
+    def backward(ctx, dsigma, _du, _dv):
+        u_new, v = ctx.saved_tensors
+        return dsigma * torch.outer(u_new, v), None, None
+
+
+class SN(object):
+    """spectral-norm mixin: one singular vector, one power iteration per forward (reference defaults)"""
+
+    def __init__(self, num_svs, num_itrs, num_outputs, transpose=False, eps=1e-12):
+        assert num_svs == 1 and num_itrs == 1, "only num_svs = num_itrs = 1 (the configurations the reference ships) is implemented"
+        self.num_itrs, self.num_svs, self.transpose, self.eps = num_itrs, num_svs, transpose, eps
+        for i in range(self.num_svs):
+            self.register_buffer('u%d' % i, torch.randn(1, num_outputs))
+            self.register_buffer('sv%d' % i, torch.ones(1))
+
+    @property
+    def u(self):
+        return [getattr(self, 'u%d' % i) for i in range(self.num_svs)]
+
+    @property
+    def sv(self):
+        return [getattr(self, 'sv%d' % i) for i in range(self.num_svs)]
+
+    def W_(self):
+        W_mat = self.weight.view(self.weight.size(0), -1)
+        if self.transpose:
+            W_mat = W_mat.t()
+        sigma, u_new, _ = _SpectralSigma.apply(W_mat, self.u0, self.eps)
+        if self.training:
+            with torch.no_grad():
+                self.u0.copy_(u_new)
+                self.sv0.copy_(sigma.reshape(1))
+        return self.weight / sigma
+
+
+class SNConv2d(nn.Conv2d, SN):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 num_svs=1, num_itrs=1, eps=1e-12):
+        nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        SN.__init__(self, num_svs, num_itrs, out_channels, eps=eps)
+
+    def forward(self, x):
+        return conv2d_gradfix.conv2d(x, self.W_().to(x.dtype), self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class SNLinear(nn.Linear, SN):
+    def __init__(self, in_features, out_features, bias=True, num_svs=1, num_itrs=1, eps=1e-12):
+        nn.Linear.__init__(self, in_features, out_features, bias)
+        SN.__init__(self, num_svs, num_itrs, out_features, eps=eps)
+
+    def forward(self, x):
+        return F.linear(x, self.W_(), self.bias)
+
+
+class SNEmbedding(nn.Embedding, SN):
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=None, max_norm=None, norm_type=2, scale_grad_by_freq=False,
+                 sparse=False, _weight=None, num_svs=1, num_itrs=1, eps=1e-12):
+        nn.Embedding.__init__(self, num_embeddings, embedding_dim, padding_idx, max_norm, norm_type, scale_grad_by_freq, sparse, _weight)
+        SN.__init__(self, num_svs, num_itrs, num_embeddings, eps=eps)
+
+    def forward(self, x):
+        return F.embedding(x, self.W_())
+
+
+# ---------------------------------------------------------------------------------------------------------------- attention
+
+def _attention_reference(theta, phi, g):
+    """softmax(theta phi^T) g with library batched GEMMs: [N,Q,D], [N,M,D], [N,M,DV] -> [N,Q,DV] (differentiable)"""
+    beta = F.softmax(torch.bmm(theta, phi.transpose(1, 2)), -1)
+    return torch.bmm(beta, g)
+
+
+class _AttentionCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, phi, g):
+        lib = _lib.load()
+        n, q, d = theta.shape
+        m, dv = g.shape[1], g.shape[2]
+        t32, p32, g32 = [t.to(torch.float32).contiguous() for t in (theta, phi, g)]
+        out = torch.empty([n, q, dv], dtype=torch.float32, device=theta.device)
+        _lib.check(lib.sbg_attention_fwd(_lib.ptr(t32), _lib.ptr(p32), _lib.ptr(g32), _lib.ptr(out), n, q, m, d, dv,
+                                         _lib.stream_ptr(theta.device)), "sbg_attention_fwd")
+        ctx.save_for_backward(theta, phi, g)
+        return out.to(theta.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        theta, phi, g = ctx.saved_tensors
+        with torch.enable_grad():       # recompute the map with differentiable library ops (keeps double-backward available)
+            ins = [t.detach().requires_grad_(True) for t in (theta, phi, g)]
+            out = _attention_reference(*ins)
+        grads = torch.autograd.grad(out, ins, dout, create_graph=torch.is_grad_enabled())
+        return tuple(grads)
+
+
+def attention_core(theta, phi, g):
+    """theta [N, Q, D], phi [N, M, D], g [N, M, DV] -> softmax(theta phi^T, -1) g"""
+    lib = _lib.load()
+    if theta.device.type == "cuda" and lib.sbg_attention_supported(theta.shape[1], phi.shape[1], theta.shape[2], g.shape[2]):
+        return _AttentionCore.apply(theta, phi, g)
+    return _attention_reference(theta, phi, g)
+
+
+class Attention(nn.Module):
+    def __init__(self, ch, which_conv=SNConv2d, name='attention'):
+        super().__init__()
+        self.ch = ch
+        self.which_conv = which_conv
+        self.theta = self.which_conv(self.ch, self.ch // 8, kernel_size=1, padding=0, bias=False)
+        self.phi = self.which_conv(self.ch, self.ch // 8, kernel_size=1, padding=0, bias=False)
+        self.g = self.which_conv(self.ch, self.ch // 2, kernel_size=1, padding=0, bias=False)
+        self.o = self.which_conv(self.ch // 2, self.ch, kernel_size=1, padding=0, bias=False)
+        self.gamma = P(torch.tensor(0.), requires_grad=True)
+
+    def forward(self, x, y=None):
+        n, _, h, w = x.shape
+        theta = self.theta(x)
+        phi = F.max_pool2d(self.phi(x), [2, 2])
+        g = F.max_pool2d(self.g(x), [2, 2])
+        # [N, C', H, W] -> [N, pixels, C'] (row-major pixels, the order of the reference's .view)
+        theta = theta.reshape(n, self.ch // 8, h * w).transpose(1, 2)
+        phi = phi.reshape(n, self.ch // 8, h * w // 4).transpose(1, 2)
+        g = g.reshape(n, self.ch // 2, h * w // 4).transpose(1, 2)
+        o = attention_core(theta, phi, g)                                  # [N, HW, C/2]
+        o = self.o(o.transpose(1, 2).reshape(n, self.ch // 2, h, w))
+        return self.gamma * o + x
+
+
+# ---------------------------------------------------------------------------------------------------------------- batch norm
+
+class _AllReduceSum(torch.autograd.Function):
+    """differentiable all-reduce(SUM) over the default process group (gradient = all-reduce(SUM) of the gradients)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        out = t.clone()
+        torch.distributed.all_reduce(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out = g.clone()
+        torch.distributed.all_reduce(out)
+        return out
+
+
+def batch_stats(x, cross_replica=False):
+    """per-channel (mean, biased var, unbiased var, count) over (N, H, W) [and over ranks]; fp32, differentiable"""
+    n, c, h, w = x.shape
+    if x.device.type == "cuda":
+        s1 = modulate.dot_hw(x).sum(0)
+        s2 = modulate.dot_hw(x, x).sum(0)
+    else:   # plumbing path for CPU-only unit tests of the host logic
+        xf = x.float()
+        s1, s2 = xf.sum([0, 2, 3]), xf.square().sum([0, 2, 3])
+    cnt = torch.full([1], float(n * h * w), dtype=torch.float32, device=x.device)
+    if cross_replica and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        packed = _AllReduceSum.apply(torch.cat([s1, s2, cnt]))
+        s1, s2, cnt = packed[:c], packed[c:2 * c], packed[2 * c:]
+    mean = s1 / cnt
+    sumvar = s2 - s1 * mean
+    return mean, sumvar / cnt, sumvar / (cnt - 1).clamp(min=1), cnt
+
+
+def normalize(x, mean, var, gain, bias, eps):
+    """(x - mean) * rsqrt(var + eps) * gain + bias with per-sample gain / bias [N, C] (or [1, C]); one streaming pass"""
+    n, c = x.shape[0], x.shape[1]
+    scale = torch.rsqrt(var + eps).reshape(1, c) * (gain.reshape(-1, c) if gain is not None else 1.0)
+    shift = (bias.reshape(-1, c) if bias is not None else 0.0) - mean.reshape(1, c) * scale
+    scale, shift = scale.expand(n, c), (shift.expand(n, c) if torch.is_tensor(shift) else torch.zeros_like(scale).expand(n, c))
+    if x.device.type == "cuda":
+        return modulate.scale_shift_nc(x, scale, shift)
+    return x * scale.reshape(n, c, 1, 1).to(x.dtype) + shift.reshape(n, c, 1, 1).to(x.dtype)
+
+
+class ccbn(nn.Module):
+    """class-conditional batch norm: gain = 1 + Emb/Linear(y), bias = Emb/Linear(y)"""
+
+    def __init__(self, output_size, input_size, which_linear, eps=1e-5, momentum=0.1, cross_replica=False, mybn=False, norm_style='bn'):
+        super().__init__()
+        self.output_size, self.input_size = output_size, input_size
+        self.gain = which_linear(input_size, output_size)
+        self.bias = which_linear(input_size, output_size)
+        self.eps, self.momentum = eps, momentum
+        self.cross_replica, self.mybn, self.norm_style = cross_replica, mybn, norm_style
+        assert norm_style in ['bn', 'nonorm'], "norm_style 'bn' (and 'nonorm') are implemented"
+        # statistics live on this module ('stored_mean' / 'stored_var', the reference's buffer names for the default path)
+        self.register_buffer('stored_mean', torch.zeros(output_size))
+        self.register_buffer('stored_var', torch.ones(output_size))
+
+    def forward(self, x, y):
+        n = y.size(0)
+        gain = (1 + self.gain(y)).view(n, -1)
+        bias = self.bias(y).view(n, -1)
+        if self.norm_style == 'nonorm':
+            return normalize(x, torch.zeros_like(self.stored_mean), torch.ones_like(self.stored_var) - self.eps, gain, bias, self.eps)
+        return _bn_forward(self, x, gain, bias, momentum=0.1)     # F.batch_norm(..., 0.1, eps) in the reference (:315-316)
+
+    def extra_repr(self):
+        return f'out: {self.output_size}, in: {self.input_size}, cross_replica={self.cross_replica}'
+
+
+class bn(nn.Module):
+    """plain batch norm with learned per-channel gain / bias"""
+
+    def __init__(self, output_size, eps=1e-5, momentum=0.1, cross_replica=False, mybn=False):
+        super().__init__()
+        self.output_size = output_size
+        self.gain = P(torch.ones(output_size), requires_grad=True)
+        self.bias = P(torch.zeros(output_size), requires_grad=True)
+        self.eps, self.momentum = eps, momentum
+        self.cross_replica, self.mybn = cross_replica, mybn
+        self.register_buffer('stored_mean', torch.zeros(output_size))
+        self.register_buffer('stored_var', torch.ones(output_size))
+
+    def forward(self, x, y=None):
+        return _bn_forward(self, x, self.gain.view(1, -1), self.bias.view(1, -1), momentum=self.momentum)
+
+
+def _bn_forward(mod, x, gain, bias, momentum):
+    if mod.training:
+        mean, var, unbiased, _ = batch_stats(x, mod.cross_replica)
+        with torch.no_grad():
+            mod.stored_mean.mul_(1 - momentum).add_(mean.detach() * momentum)
+            mod.stored_var.mul_(1 - momentum).add_(unbiased.detach() * momentum)
+    else:
+        mean, var = mod.stored_mean, mod.stored_var
+    return normalize(x, mean, var, gain, bias, mod.eps)
+
+
+# ---------------------------------------------------------------------------------------------------------------- residual blocks
+
+class GBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, which_conv=nn.Conv2d, which_bn=bn, activation=None, upsample=None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.which_conv, self.which_bn = which_conv, which_bn
+        self.activation = activation
+        self.upsample = upsample
+        self.conv1 = self.which_conv(self.in_channels, self.out_channels)
+        self.conv2 = self.which_conv(self.out_channels, self.out_channels)
+        self.learnable_sc = in_channels != out_channels or upsample
+        if self.learnable_sc:
+            self.conv_sc = self.which_conv(in_channels, out_channels, kernel_size=1, padding=0)
+        self.bn1 = self.which_bn(in_channels)
+        self.bn2 = self.which_bn(out_channels)
+
+    def forward(self, x, y):
+        h = self.activation(self.bn1(x, y))
+        if self.upsample:
+            h = self.upsample(h)
+            x = self.upsample(x)
+        h = self.conv1(h)
+        h = self.activation(self.bn2(h, y))
+        h = self.conv2(h)
+        if self.learnable_sc:
+            x = self.conv_sc(x)
+        return h + x
+
+
+class DBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, which_conv=SNConv2d, wide=True, preactivation=False, activation=None, downsample=None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.hidden_channels = self.out_channels if wide else self.in_channels
+        self.which_conv = which_conv
+        self.preactivation = preactivation
+        self.activation = activation
+        self.downsample = downsample
+        self.conv1 = self.which_conv(self.in_channels, self.hidden_channels)
+        self.conv2 = self.which_conv(self.hidden_channels, self.out_channels)
+        self.learnable_sc = True if (in_channels != out_channels) or downsample else False
+        if self.learnable_sc:
+            self.conv_sc = self.which_conv(in_channels, out_channels, kernel_size=1, padding=0)
+
+    def shortcut(self, x):
+        if self.preactivation:
+            if self.learnable_sc:
+                x = self.conv_sc(x)
+            if self.downsample:
+                x = self.downsample(x)
+        else:
+            if self.downsample:
+                x = self.downsample(x)
+            if self.learnable_sc:
+                x = self.conv_sc(x)
+        return x
+
+    def forward(self, x):
+        h = self.activation(x) if self.preactivation else x     # out-of-place ReLU (it must not touch the shortcut's input)
+        h = self.conv1(h)
+        h = self.conv2(self.activation(h))
+        if self.downsample:
+            h = self.downsample(h)
+        return h + self.shortcut(x)

@@ -10,7 +10,7 @@
 
 namespace {
 
-struct ScaleArgs { const void* x; const float* a; const float* z; void* y; int N, C; int64_t HW, zsn, total; };
+struct ScaleArgs { const void* x; const float* a; const float* z; const float* bnc; void* y; int N, C; int64_t HW, zsn, total; };
 
 // channel-minor: one lane = 8 channels of one pixel.
 template <class T>
@@ -25,8 +25,15 @@ __global__ __launch_bounds__(256) void scale_nc_cminor8(ScaleArgs p)
         Vec8<T>::ld(px + (i << 3), v);
         Vec8<float>::ld(p.a + (int64_t)n * p.C + c, a);
         const float z = p.z ? p.z[n * p.zsn + pix] : 0.f;
+        if (p.bnc) {
+            float b[8];
+            Vec8<float>::ld(p.bnc + (int64_t)n * p.C + c, b);
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = v[j] * a[j] + z;
+            for (int j = 0; j < 8; j++) v[j] = v[j] * a[j] + (z + b[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = v[j] * a[j] + z;
+        }
         Vec8<T>::st(py + (i << 3), v);
     }
 }
@@ -41,7 +48,7 @@ __global__ __launch_bounds__(256) void scale_nc_scalar(ScaleArgs p, int layout)
         int c, n; int64_t pix;
         if (layout == 1) { c = (int)(i % p.C); const int64_t r = i / p.C; pix = r % p.HW; n = (int)(r / p.HW); }
         else             { pix = i % p.HW; const int64_t r = i / p.HW; c = (int)(r % p.C); n = (int)(r / p.C); }
-        const float z = p.z ? p.z[n * p.zsn + pix] : 0.f;
+        const float z = (p.z ? p.z[n * p.zsn + pix] : 0.f) + (p.bnc ? p.bnc[(int64_t)n * p.C + c] : 0.f);
         Elem<T>::st(py + i, Elem<T>::ld(px + i) * p.a[(int64_t)n * p.C + c] + z);
     }
 }
@@ -177,20 +184,33 @@ static int run_dot(const DotArgs& a, int layout, bool fast, hipStream_t s)
 
 } // namespace
 
-extern "C" int sbg_scale_nc(const void* x, const float* a, const float* z, void* y, int dtype, int layout,
-                            int N, int C, int64_t HW, int64_t z_stride_n, sbg_stream_t stream)
+static int scale_impl(const void* x, const float* a, const float* z, const float* bnc, void* y, int dtype, int layout,
+                      int N, int C, int64_t HW, int64_t z_stride_n, sbg_stream_t stream)
 {
     SBG_CHECK(x && a && y, "scale_nc: null pointer");
     SBG_CHECK(dtype == SBG_F32 || dtype == SBG_F16 || dtype == SBG_BF16, "scale_nc: unsupported dtype %d", dtype);
     SBG_CHECK(layout == 0 || layout == 1, "scale_nc: layout must be 0 (planar) or 1 (channel-minor)");
     SBG_CHECK(N >= 0 && C >= 1 && HW >= 0, "scale_nc: bad sizes");
     if ((int64_t)N * C * HW == 0) return SBG_OK;
-    ScaleArgs p; p.x = x; p.a = a; p.z = z; p.y = y; p.N = N; p.C = C; p.HW = HW; p.zsn = z_stride_n; p.total = 0;
-    const bool vec = layout == 1 && (C % 8) == 0 && sbg_aligned16(x) && sbg_aligned16(y) && sbg_aligned16(a);
+    ScaleArgs p; p.x = x; p.a = a; p.z = z; p.bnc = bnc; p.y = y; p.N = N; p.C = C; p.HW = HW; p.zsn = z_stride_n; p.total = 0;
+    const bool vec = layout == 1 && (C % 8) == 0 && sbg_aligned16(x) && sbg_aligned16(y) && sbg_aligned16(a) && (!bnc || sbg_aligned16(bnc));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SBG_F32) return run_scale<float>(p, layout, vec, s);
     if (dtype == SBG_F16) return run_scale<f16_s>(p, layout, vec, s);
     return run_scale<bf16_s>(p, layout, vec, s);
+}
+
+extern "C" int sbg_scale_nc(const void* x, const float* a, const float* z, void* y, int dtype, int layout,
+                            int N, int C, int64_t HW, int64_t z_stride_n, sbg_stream_t stream)
+{
+    return scale_impl(x, a, z, nullptr, y, dtype, layout, N, C, HW, z_stride_n, stream);
+}
+
+extern "C" int sbg_scale_shift_nc(const void* x, const float* a, const float* b, void* y, int dtype, int layout,
+                                  int N, int C, int64_t HW, sbg_stream_t stream)
+{
+    SBG_CHECK(b != nullptr, "scale_shift_nc: null shift");
+    return scale_impl(x, a, nullptr, b, y, dtype, layout, N, C, HW, 0, stream);
 }
 
 extern "C" int sbg_dot_hw_splits(int layout, int N, int C, int64_t HW)

@@ -97,6 +97,43 @@ class _DotHW(torch.autograd.Function):
         return du, dv
 
 
+class _ScaleShiftNC(torch.autograd.Function):
+    """y = x * a[n, c] + b[n, c];  a, b: fp32 [N, C]  (normalise-and-modulate step of the batch-norm layers)"""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        lib = _lib.load()
+        _lib.require_cuda(x, "scale_shift_nc")
+        xd, layout = _layout(x)
+        n, c, h, w = xd.shape
+        a32 = a.reshape(n, c).to(torch.float32).contiguous()
+        b32 = b.reshape(n, c).to(torch.float32).contiguous()
+        y = torch.empty_like(xd)
+        _lib.check(lib.sbg_scale_shift_nc(_lib.ptr(xd), _lib.ptr(a32), _lib.ptr(b32), _lib.ptr(y), _lib.dtype_code(xd.dtype), layout,
+                                          n, c, h * w, _lib.stream_ptr(xd.device)), "sbg_scale_shift_nc")
+        ctx.save_for_backward(x, a)
+        ctx.b_meta = (b.shape, b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        dx = da = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _ScaleNC.apply(dy, a, None)
+        if ctx.needs_input_grad[1]:
+            da = _DotHW.apply(dy, x).to(a.dtype).reshape(a.shape)
+        if ctx.needs_input_grad[2]:
+            db = _DotHW.apply(dy, None).to(ctx.b_meta[1]).reshape(ctx.b_meta[0])
+        return dx, da, db
+
+
+def scale_shift_nc(x, a, b):
+    """x: [N, C, H, W]; a, b: [N, C] -> x * a + b (per sample and channel)"""
+    n, c = x.shape[0], x.shape[1]
+    return _ScaleShiftNC.apply(x, a.reshape(n, c), b.reshape(n, c))
+
+
 def scale_nc(x, a, z=None):
     """x: [N, C, H, W]; a: [N, C] (any float dtype, used in fp32); z: None, [N, 1, H, W] or [H, W] -> x * a (+ z)"""
     assert x.ndim == 4 and a.numel() == x.shape[0] * x.shape[1]

@@ -267,3 +267,82 @@ class Discriminator32_dcgan(Discriminator_dcgan):
 class Discriminator48_dcgan(Discriminator_dcgan):
     def __init__(self):
         super().__init__(M=48)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BigGAN discriminator (reference :699-842): spectral-norm residual blocks, self-attention, projection head
+
+def D_arch(ch=64, attention='64', ksize='333333', dilation='111111'):
+    att = [int(item) for item in attention.split('_')]
+    arch = {}
+    arch[256] = {'in_channels': [3] + [ch * m for m in [1, 2, 4, 8, 8, 16]], 'out_channels': [ch * m for m in [1, 2, 4, 8, 8, 16, 16]],
+                 'downsample': [True] * 6 + [False], 'resolution': [128, 64, 32, 16, 8, 4, 4]}
+    arch[128] = {'in_channels': [3] + [ch * m for m in [1, 2, 4, 8, 16]], 'out_channels': [ch * m for m in [1, 2, 4, 8, 16, 16]],
+                 'downsample': [True] * 5 + [False], 'resolution': [64, 32, 16, 8, 4, 4]}
+    arch[64] = {'in_channels': [3] + [ch * m for m in [1, 2, 4, 8]], 'out_channels': [ch * m for m in [1, 2, 4, 8, 16]],
+                'downsample': [True] * 4 + [False], 'resolution': [32, 16, 8, 4, 4]}
+    arch[32] = {'in_channels': [3] + [ch * m for m in [4, 4, 4]], 'out_channels': [ch * m for m in [4, 4, 4, 4]],
+                'downsample': [True, True, False, False], 'resolution': [16, 16, 16, 16]}
+    for res, a in arch.items():
+        top = 8 if res > 32 else 6
+        a['attention'] = {2 ** i: (2 ** i in att) for i in range(2, top)}
+    return arch
+
+
+@discriminators.add_to_registry("big_gan")
+class BigGanDiscriminator(torch.nn.Module):
+    def __init__(self, z_dim=128, c_dim=10, D_ch=64, D_wide=True, img_resolution=128,
+                 D_kernel_size=3, D_attn='64', n_classes=10,
+                 num_D_SVs=1, num_D_SV_itrs=1, D_activation='relu',
+                 SN_eps=1e-12, output_dim=1, D_mixed_precision=False, D_fp16=False,
+                 D_init='ortho', D_param='SN', **kwargs):
+        super().__init__()
+        import functools
+        from ..biggan import layers
+        self.z_dim, self.c_dim, self.ch, self.D_wide = z_dim, c_dim, D_ch, D_wide
+        self.img_resolution, self.kernel_size, self.attention, self.n_classes = img_resolution, D_kernel_size, D_attn, n_classes
+        assert D_activation == 'relu'
+        self.activation = layers.ReLU()
+        self.init, self.D_param, self.SN_eps, self.fp16 = D_init, D_param, SN_eps, D_fp16
+        self.arch = D_arch(self.ch, self.attention)[img_resolution]
+        assert self.D_param == 'SN'
+        sn = dict(num_svs=num_D_SVs, num_itrs=num_D_SV_itrs, eps=self.SN_eps)
+        self.which_conv = functools.partial(layers.SNConv2d, kernel_size=3, padding=1, **sn)
+        self.which_linear = functools.partial(layers.SNLinear, **sn)
+        self.which_embedding = functools.partial(layers.SNEmbedding, **sn)
+        blocks = []
+        for index in range(len(self.arch['out_channels'])):
+            stage = [layers.DBlock(in_channels=self.arch['in_channels'][index], out_channels=self.arch['out_channels'][index],
+                                   which_conv=self.which_conv, wide=self.D_wide, activation=self.activation, preactivation=(index > 0),
+                                   downsample=(layers.avg_pool2x if self.arch['downsample'][index] else None))]
+            if self.arch['attention'][self.arch['resolution'][index]]:
+                stage.append(layers.Attention(self.arch['out_channels'][index], self.which_conv))
+            blocks.append(torch.nn.ModuleList(stage))
+        self.blocks = torch.nn.ModuleList(blocks)
+        self.linear = self.which_linear(self.arch['out_channels'][-1], output_dim)
+        self.embed = self.which_embedding(self.n_classes, self.arch['out_channels'][-1])
+        self.init_weights()
+
+    def init_weights(self):
+        self.param_count = 0
+        for module in self.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.Linear, torch.nn.Embedding)):
+                if self.init == 'ortho':
+                    torch.nn.init.orthogonal_(module.weight)
+                elif self.init == 'N02':
+                    torch.nn.init.normal_(module.weight, 0, 0.02)
+                elif self.init in ['glorot', 'xavier']:
+                    torch.nn.init.xavier_uniform_(module.weight)
+                self.param_count += sum(p.data.nelement() for p in module.parameters())
+
+    def forward(self, x, c=None):
+        from ..torch_utils.ops import modulate
+        y = torch.argmax(c, dim=1) if c is not None else None
+        h = x
+        for blocklist in self.blocks:
+            for block in blocklist:
+                h = block(h)
+        h = self.activation(h)
+        h = modulate.dot_hw(h).to(h.dtype) if h.device.type == 'cuda' else torch.sum(h, [2, 3])      # global sum pooling
+        out = self.linear(h)
+        return out + torch.sum(self.embed(y) * h, 1, keepdim=True)

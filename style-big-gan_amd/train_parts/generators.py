@@ -498,3 +498,103 @@ class Generator32_dcgan(Generator_dcgan):
 class Generator48_dcgan(Generator_dcgan):
     def __init__(self, z_dim):
         super().__init__(z_dim, M=4)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BigGAN (reference :720-937): spectral-norm convolutions, class-conditional batch norm, optional self-attention
+
+def G_arch(ch=64, attention='64', ksize='333333', dilation='111111'):
+    """channel / resolution schedule per output resolution (reference :720-753)"""
+    att = [int(item) for item in attention.split('_')]
+    table = {512: ([16, 16, 8, 8, 4, 2, 1], [16, 8, 8, 4, 2, 1, 1]), 256: ([16, 16, 8, 8, 4, 2], [16, 8, 8, 4, 2, 1]),
+             128: ([16, 16, 8, 4, 2], [16, 8, 4, 2, 1]), 64: ([16, 16, 8, 4], [16, 8, 4, 2]), 32: ([4, 4, 4], [4, 4, 4])}
+    arch = {}
+    for res, (cin, cout) in table.items():
+        resolutions = [2 ** i for i in range(3, int(np.log2(res)) + 1)]
+        arch[res] = {'in_channels': [ch * m for m in cin], 'out_channels': [ch * m for m in cout], 'upsample': [True] * len(cin),
+                     'resolution': resolutions, 'attention': {r: (r in att) for r in resolutions}}
+    return arch
+
+
+@generators.add_to_registry("big_gan")
+class BigGAnGenerator(torch.nn.Module):
+    def __init__(self, G_ch=64, z_dim=128, c_dim=10, bottom_width=4, img_resolution=128,
+                 G_kernel_size=3, G_attn='64', n_classes=10,
+                 num_G_SVs=1, num_G_SV_itrs=1,
+                 G_shared=True, shared_dim=0, hier=False,
+                 cross_replica=False, mybn=False,
+                 G_activation='relu',
+                 BN_eps=1e-5, SN_eps=1e-12, G_mixed_precision=False, G_fp16=False,
+                 G_init='ortho',
+                 G_param='SN', norm_style='bn',
+                 **kwargs):
+        super().__init__()
+        import functools
+        from ..biggan import layers
+        self.c_dim, self.ch, self.z_dim = c_dim, G_ch, z_dim
+        self.bottom_width, self.img_resolution = bottom_width, img_resolution
+        self.kernel_size, self.attention, self.n_classes = G_kernel_size, G_attn, n_classes
+        self.G_shared = G_shared
+        self.shared_dim = shared_dim if shared_dim > 0 else z_dim
+        self.hier, self.cross_replica, self.mybn = hier, cross_replica, mybn
+        assert G_activation == 'relu'
+        self.activation = layers.ReLU()
+        self.init, self.G_param, self.norm_style = G_init, G_param, norm_style
+        self.BN_eps, self.SN_eps, self.fp16 = BN_eps, SN_eps, G_fp16
+        self.arch = G_arch(self.ch, self.attention)[img_resolution]
+        if self.hier:
+            self.num_slots = len(self.arch['in_channels']) + 1
+            self.z_chunk_size = self.z_dim // self.num_slots
+            self.z_dim = self.z_chunk_size * self.num_slots
+        else:
+            self.num_slots, self.z_chunk_size = 1, 0
+
+        assert self.G_param == 'SN', "G_param='SN' (the shipped configuration) is implemented"
+        self.which_conv = functools.partial(layers.SNConv2d, kernel_size=3, padding=1, num_svs=num_G_SVs, num_itrs=num_G_SV_itrs, eps=self.SN_eps)
+        self.which_linear = functools.partial(layers.SNLinear, num_svs=num_G_SVs, num_itrs=num_G_SV_itrs, eps=self.SN_eps)
+        self.which_embedding = torch.nn.Embedding
+        bn_linear = functools.partial(self.which_linear, bias=False) if self.G_shared else self.which_embedding
+        self.which_bn = functools.partial(layers.ccbn, which_linear=bn_linear, cross_replica=self.cross_replica, mybn=self.mybn,
+                                          input_size=(self.shared_dim + self.z_chunk_size if self.G_shared else self.n_classes),
+                                          norm_style=self.norm_style, eps=self.BN_eps)
+        self.shared = self.which_embedding(n_classes, self.shared_dim) if G_shared else layers.identity()
+        self.linear = self.which_linear(self.z_dim // self.num_slots, self.arch['in_channels'][0] * (self.bottom_width ** 2))
+        blocks = []
+        for index in range(len(self.arch['out_channels'])):
+            stage = [layers.GBlock(in_channels=self.arch['in_channels'][index], out_channels=self.arch['out_channels'][index],
+                                   which_conv=self.which_conv, which_bn=self.which_bn, activation=self.activation,
+                                   upsample=(layers.nearest_upsample2x if self.arch['upsample'][index] else None))]
+            if self.arch['attention'][self.arch['resolution'][index]]:
+                stage.append(layers.Attention(self.arch['out_channels'][index], self.which_conv))
+            blocks.append(torch.nn.ModuleList(stage))
+        self.blocks = torch.nn.ModuleList(blocks)
+        self.output_layer = torch.nn.Sequential(layers.bn(self.arch['out_channels'][-1], cross_replica=self.cross_replica, mybn=self.mybn),
+                                                self.activation, self.which_conv(self.arch['out_channels'][-1], 3))
+        self.init_weights()
+
+    def init_weights(self):
+        self.param_count = 0
+        for module in self.modules():
+            if isinstance(module, (torch.nn.Conv2d, torch.nn.Linear, torch.nn.Embedding)):
+                if self.init == 'ortho':
+                    torch.nn.init.orthogonal_(module.weight)
+                elif self.init == 'N02':
+                    torch.nn.init.normal_(module.weight, 0, 0.02)
+                elif self.init in ['glorot', 'xavier']:
+                    torch.nn.init.xavier_uniform_(module.weight)
+                self.param_count += sum(p.data.nelement() for p in module.parameters())
+
+    def forward(self, z, c, noise_mode='random'):
+        y = torch.argmax(c, dim=1)      # the reference feeds class indices (G_shared=False: embedding lookup inside ccbn)
+        if self.hier:
+            zs = torch.split(z, self.z_chunk_size, 1)
+            z = zs[0]
+            ys = [torch.cat([y, item], 1) for item in zs[1:]]
+        else:
+            ys = [y] * len(self.blocks)
+        h = self.linear(z)
+        h = h.view(h.size(0), -1, self.bottom_width, self.bottom_width)
+        for index, blocklist in enumerate(self.blocks):
+            for block in blocklist:
+                h = block(h, ys[index])
+        return torch.tanh(self.output_layer(h))

@@ -231,7 +231,128 @@ def gen_networks():
         save(f"networks_{tag}", arrays, meta)
 
 
+# ---------------------------------------------------------------------------------------------------------------- BigGAN
+
+def _import_train_parts():
+    """train_parts.* imports omegaconf only for the MISSING sentinel (utils.py:91); a two-line in-memory stand-in for that
+    absent package is enough to import the reference's model classes.  Nothing of it is written anywhere."""
+    import types
+    if 'omegaconf' not in sys.modules:
+        stub = types.ModuleType('omegaconf')
+        stub.MISSING = '???'
+        sys.modules['omegaconf'] = stub
+    import train_parts.generators as RG
+    import train_parts.discriminators as RD
+    return RG, RD
+
+
+def gen_biggan():
+    import biggan.layers as RL
+    arrays = {}
+    # -- power iteration / SN
+    torch.manual_seed(300)
+    W = torch.randn(12, 20)
+    u = torch.randn(1, 12)
+    arrays.update({"pi/W": npy(W), "pi/u": npy(u)})
+    svs, us, vs = RL.power_iteration(W, [u.clone()], update=False, eps=1e-12)
+    arrays.update({"pi/sigma": npy(svs[0]), "pi/u_new": npy(us[0]), "pi/v": npy(vs[0])})
+    conv = RL.SNConv2d(8, 12, 3, padding=1)
+    conv.train()
+    x = torch.randn(2, 8, 6, 6, requires_grad=True)
+    arrays.update({f"snconv/sd/{k}": npy(v) for k, v in conv.state_dict().items()})
+    y = conv(x)
+    gx, gw = torch.autograd.grad(y.square().sum(), [x, conv.weight])
+    arrays.update({"snconv/x": npy(x), "snconv/y_train": npy(y), "snconv/dx": npy(gx), "snconv/dw": npy(gw),
+                   "snconv/u0_after": npy(conv.u0), "snconv/sv0_after": npy(conv.sv0)})
+    conv.eval()
+    arrays["snconv/y_eval"] = npy(conv(x))
+    lin = RL.SNLinear(10, 6)
+    lin.train()
+    arrays.update({f"snlin/sd/{k}": npy(v) for k, v in lin.state_dict().items()})
+    xl = torch.randn(4, 10)
+    arrays.update({"snlin/x": npy(xl), "snlin/y": npy(lin(xl))})
+    # -- attention
+    att = RL.Attention(16)
+    att.train()
+    with torch.no_grad():
+        att.gamma.fill_(0.7)
+    arrays.update({f"att/sd/{k}": npy(v) for k, v in att.state_dict().items()})
+    xa = torch.randn(2, 16, 8, 8, requires_grad=True)
+    ya = att(xa)
+    ga = torch.autograd.grad(ya.square().sum(), [xa] + list(att.parameters()), create_graph=True)
+    arrays.update({"att/x": npy(xa), "att/y": npy(ya), "att/dx": npy(ga[0])})
+    for (name, _), g_ in zip(att.named_parameters(), ga[1:]):
+        arrays[f"att/grad/{name}"] = npy(g_)
+    g2 = torch.autograd.grad(ga[0].square().sum(), xa)[0]          # R1-style second order through attention
+    arrays["att/d2x"] = npy(g2)
+    # -- batch norms
+    emb = torch.nn.Embedding
+    cc = RL.ccbn(6, 10, emb)
+    cc.train()
+    arrays.update({f"ccbn/sd/{k}": npy(v) for k, v in cc.state_dict().items()})
+    xb = (torch.randn(4, 6, 5, 5) * 2 + 1).requires_grad_(True)
+    yb_idx = torch.tensor([1, 3, 3, 7])
+    yb = cc(xb, yb_idx)
+    gb = torch.autograd.grad(yb.square().sum(), [xb, cc.gain.weight, cc.bias.weight])
+    arrays.update({"ccbn/x": npy(xb), "ccbn/y_idx": yb_idx.numpy().astype(np.float32), "ccbn/y_train": npy(yb), "ccbn/dx": npy(gb[0]),
+                   "ccbn/dgain": npy(gb[1]), "ccbn/dbias": npy(gb[2]), "ccbn/mean_after": npy(cc.stored_mean), "ccbn/var_after": npy(cc.stored_var)})
+    cc.eval()
+    arrays["ccbn/y_eval"] = npy(cc(xb, yb_idx))
+    b = RL.bn(6)
+    b.train()
+    with torch.no_grad():
+        b.gain.copy_(torch.rand(6) + 0.5); b.bias.copy_(torch.randn(6))
+    arrays.update({f"bn/sd/{k}": npy(v) for k, v in b.state_dict().items()})
+    ybn = b(xb)
+    arrays.update({"bn/y_train": npy(ybn), "bn/mean_after": npy(b.stored_mean), "bn/var_after": npy(b.stored_var)})
+    # synchronized-BN formula (sync_batchnorm/batchnorm.py:147-158) on explicit sums
+    s1, s2, cnt = xb.detach().sum([0, 2, 3]), xb.detach().square().sum([0, 2, 3]), 4 * 25
+    mean = s1 / cnt; sumvar = s2 - s1 * mean
+    arrays.update({"syncbn/mean": npy(mean), "syncbn/inv_std": npy(torch.rsqrt(sumvar / cnt + 1e-5)), "syncbn/unbias_var": npy(sumvar / (cnt - 1))})
+    save("biggan_layers", arrays, dict())
+
+    # -- whole tiny BigGAN G / D at 32x32 (ch 8), attention in both, hinge losses
+    RG, RD = _import_train_parts()
+    torch.manual_seed(301)
+    cfg = dict(G_ch=8, D_ch=8, z_dim=16, n_classes=10, img_resolution=32, G_attn='16', D_attn='16')
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        G = RG.generators['big_gan'](G_ch=8, z_dim=16, c_dim=10, img_resolution=32, G_shared=False, G_attn='16', G_init='N02', n_classes=10)
+        D = RD.discriminators['big_gan'](D_ch=8, c_dim=10, img_resolution=32, D_attn='16', D_init='N02', n_classes=10)
+    with torch.no_grad():
+        for m in list(G.modules()) + list(D.modules()):
+            if isinstance(m, RL.Attention):
+                m.gamma.fill_(0.5)
+        for name, p_ in list(G.named_parameters()) + list(D.named_parameters()):
+            if p_.ndim > 1:
+                p_.mul_(8.0)        # N02 init is tiny at this width; scale up so every path carries signal
+    G.train(); D.train()
+    arrays = {}
+    arrays.update(state_arrays(G, "G")); arrays.update(state_arrays(D, "D"))
+    n = 4
+    z = torch.randn(n, 16)
+    c = torch.nn.functional.one_hot(torch.tensor([0, 3, 3, 9]), 10).float()
+    real = torch.randn(n, 3, 32, 32)
+    arrays.update(z=npy(z), c=npy(c), real=npy(real))
+    img = G(z, c)
+    logits_fake = D(img, c)
+    loss_g = -logits_fake.mean()
+    gG = torch.autograd.grad(loss_g, list(G.parameters()), allow_unused=True, retain_graph=True)
+    arrays.update(img=npy(img), logits_fake=npy(logits_fake), loss_g=npy(loss_g))
+    for (name, p_), g_ in zip(G.named_parameters(), gG):
+        arrays[f"gradG/{name}"] = npy(g_ if g_ is not None else torch.zeros_like(p_))
+    arrays.update({f"G_after/{k}": npy(v) for k, v in G.state_dict().items() if ('u0' in k or 'sv0' in k or 'stored' in k)})
+    arrays.update({f"D_after1/{k}": npy(v) for k, v in D.state_dict().items() if ('u0' in k or 'sv0' in k)})
+    logits_real = D(real, c)
+    loss_d = torch.nn.functional.relu(1 - logits_real).mean() + torch.nn.functional.relu(1 + D(img.detach(), c)).mean()
+    gD = torch.autograd.grad(loss_d, list(D.parameters()), allow_unused=True)
+    arrays.update(logits_real=npy(logits_real), loss_d=npy(loss_d))
+    for (name, p_), g_ in zip(D.named_parameters(), gD):
+        arrays[f"gradD/{name}"] = npy(g_ if g_ is not None else torch.zeros_like(p_))
+    save("biggan_networks", arrays, cfg)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks"]
+    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks", "biggan"]
     for name in which:
         globals()["gen_" + name]()
