@@ -13,6 +13,7 @@ as their last gradient of the phase's final accumulation round has been written,
 of backward; ``nan_to_num`` and Adam run over the flat buckets / foreach lists instead of per-parameter launches.
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -144,3 +145,151 @@ class StepEngine:
         torch._foreach_lerp_(p_ema, p, 1.0 - beta)      # p_ema + (p - p_ema) * (1 - beta) == p.lerp(p_ema, beta)
         for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
             b_ema.copy_(b)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Config-driven trainers: the lifecycle `starter.multiprocesses_main` drives (reference starter.py:32-45), over StepEngine.
+
+class SyntheticDataset:
+    """Stands in for the reference's ImageFolderDataset (out of scope: the metric uses synthetic reals): uint8 U[0, 255]
+    images and uniformly drawn one-hot labels, exposing the properties the trainer reads (train_parts/datasets.py:129-157)."""
+
+    def __init__(self, resolution=32, num_channels=3, num_classes=0, seed=0):
+        self.resolution, self.num_channels, self.label_dim = resolution, num_channels, num_classes
+        self.image_shape = [num_channels, resolution, resolution]
+        self.has_labels = num_classes > 0
+        self._gen = torch.Generator().manual_seed(seed)
+
+    def batch(self, n, device):
+        img = torch.randint(0, 256, [n] + self.image_shape, generator=self._gen, dtype=torch.uint8).to(device)
+        if self.has_labels:
+            idx = torch.randint(0, self.label_dim, [n], generator=self._gen)
+            c = torch.nn.functional.one_hot(idx, self.label_dim).float().to(device)
+        else:
+            c = torch.zeros([n, 0], device=device)
+        return img, c
+
+
+@trainers.add_to_registry("base")
+class BaseTrainer:
+    """One data-parallel G / D pair (reference BaseTrainer :155-876, hot path only)."""
+
+    split_generator = False      # SG2Trainer synchronises mapping and synthesis separately
+
+    def __init__(self):
+        self.rank = 0
+        self.config = None
+
+    # -- argument assembly / validation (reference :155-395) -----------------------------------------------------------
+    def setup_arguments(self, config):
+        gen, perf = config.gen, config.perf
+        gpus = int(perf.gpus)
+        if gpus < 1 or gpus & (gpus - 1):
+            raise ValueError("perf.gpus must be a power of two")
+        if gen.batch < 1 or gen.batch_gpu < 1:
+            raise ValueError("gen.batch and gen.batch_gpu must be set")
+        batch_gpu = min(gen.batch_gpu, gen.batch // gpus)
+        if gen.batch % gpus != 0 or gen.batch % (gpus * batch_gpu) != 0:
+            raise ValueError("gen.batch must be a multiple of perf.gpus * gen.batch_gpu")
+        if config.aug.aug != "noaug":
+            raise NotImplementedError("ADA augmentation is outside this build's hot path: run with aug.aug=noaug")
+        if config.data.dataset != "synthetic":
+            raise NotImplementedError("dataset loading is outside this build's hot path: run with data.dataset=synthetic "
+                                      "(data.resolution=<R> data.num_classes=<K>)")
+        if config.trans.resume != "noresume":
+            raise NotImplementedError("snapshot resume is outside this build's hot path")
+        self.config = config
+        self.num_gpus, self.batch_size, self.batch_gpu = gpus, gen.batch, batch_gpu
+        self.dataset = SyntheticDataset(int(config.data.get("resolution", 32)), 3,
+                                        int(config.data.get("num_classes", 0)) if config.data.cond else 0, seed=gen.seed)
+        common = dict(c_dim=self.dataset.label_dim, img_resolution=self.dataset.resolution, img_channels=self.dataset.num_channels)
+        self.G_kwargs = self._model_kwargs(config.gens_args[gen.generator], common)
+        self.D_kwargs = self._model_kwargs(config.discs_args[gen.discriminator], common)
+        strip = lambda d: {k: v for k, v in d.items() if k != "params"}
+        self.G_opt = (gen.optim_gen, strip(config.optim_gen_args[gen.optim_gen]))
+        self.D_opt = (gen.optim_disc, strip(config.optim_disc_args[gen.optim_disc]))
+        self.gen_regs = [(name, dict(config.gen_regs_all[name])) for name in gen.gen_regs]
+        self.dis_regs = [(name, dict(config.disc_regs_all[name])) for name in gen.disc_regs]
+        la = dict(config.losses_arch_args[gen.loss_arch])
+        self.loss_arch_kwargs = {k: v for k, v in la.items() if k not in ("args", "G_mapping", "G_synthesis") and v != utils.MISSING}
+        self.ema_kimg = config.ema.kimg
+        self.ema_rampup = config.ema.ramp if config.ema.ramp >= 0 else None
+        self.total_kimg = gen.kimg
+        return self
+
+    @staticmethod
+    def _model_kwargs(group, common):
+        import inspect
+        kw = {k: (dict(v) if isinstance(v, dict) else v) for k, v in group.items() if not (isinstance(v, str) and v == utils.MISSING)}
+        kw = {k: v for k, v in kw.items() if k not in ("args", "kwargs")}
+        kw.update({k: v for k, v in common.items() if k in group or k in ("c_dim", "img_resolution", "img_channels")})
+        return kw
+
+    # -- lifecycle ------------------------------------------------------------------------------------------------------
+    def setup_logs(self):
+        self.stats = training_stats.Collector(regex=".*")
+
+    def distribute_torch(self, temp_dir):
+        if self.num_gpus > 1:
+            init_file = os.path.abspath(os.path.join(temp_dir, ".torch_distributed_init"))
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            torch.distributed.init_process_group(backend=backend, init_method=f"file://{init_file}", rank=self.rank, world_size=self.num_gpus)
+        sync_device = self.device() if self.num_gpus > 1 else None
+        training_stats.init_multiprocessing(rank=self.rank, sync_device=sync_device)
+
+    def device(self):
+        return torch.device("cuda", self.rank) if torch.cuda.is_available() else torch.device("cpu")
+
+    def init_params(self):
+        seed = self.config.gen.seed
+        np.random.seed(seed * self.num_gpus + self.rank)
+        torch.manual_seed(seed * self.num_gpus + self.rank)
+
+    def setup_dataset(self):
+        pass        # synthetic batches are drawn on demand
+
+    def setup_networks(self):
+        gen = self.config.gen
+        n_dis = int(gen.n_dis)
+        self.engine = StepEngine(self.device(), generator=gen.generator, discriminator=gen.discriminator, gen_kwargs=self.G_kwargs,
+                                 disc_kwargs=self.D_kwargs, loss_arch=gen.loss_arch, loss=gen.loss, loss_arch_kwargs=self.loss_arch_kwargs,
+                                 gen_regs=self.gen_regs, dis_regs=self.dis_regs, optim_gen=self.G_opt, optim_disc=self.D_opt,
+                                 g_reg_interval=gen.g_reg_interval, d_reg_interval=gen.d_reg_interval,
+                                 batch=self.batch_size // self.num_gpus, batch_gpu=self.batch_gpu, ema_kimg=self.config.ema.kimg,
+                                 ema_rampup=self.ema_rampup, use_ema=self.config.ema.use_ema, world_size=self.num_gpus, rank=self.rank,
+                                 seed=gen.seed)
+        if n_dis > 1:       # the generator phase runs every n_dis-th iteration (reference :609-610)
+            for phase in self.engine.phases:
+                if phase.name.startswith("G"):
+                    phase.interval = phase.interval * n_dis
+
+    def setup_augmentations(self):
+        pass
+
+    def distrib_acrros_gpu(self):
+        pass        # StepEngine wraps its modules in GradReducer at construction (broadcast of rank 0's weights included)
+
+    def setup_training_phases(self):
+        return self.engine.phases
+
+    def export_sample_images(self):
+        pass
+
+    def training_loop(self, max_iterations=None):
+        eng = self.engine
+        total = self.total_kimg * 1000
+        it = 0
+        while (max_iterations is None or it < max_iterations) and (total < 0 or eng.cur_nimg < total or it == 0):
+            img, c = self.dataset.batch(eng.batch, eng.device)
+            eng.train_iteration(img.to(torch.float32) / 127.5 - 1, c)
+            it += 1
+            if max_iterations is None and total >= 0 and eng.cur_nimg >= total:
+                break
+        self.stats.update()
+        return it
+
+
+@trainers.add_to_registry("sg2")
+class SG2Trainer(BaseTrainer):
+    """StyleGAN2 trainer: the generator's mapping and synthesis networks are separate data-parallel modules (reference :881-893)."""
+    split_generator = True
