@@ -86,8 +86,11 @@ int sbg_upfirdn2d(const sbg_upfirdn2d_params* p, sbg_stream_t stream);
  * over the launch's output grid OH x OW (out-of-range input pixels read as zero).
  * x: [N, IH, IW, Cin] channel-minor (Cin % 8 == 0, pixel stride xs_w etc. in elements),
  * w: packed [nslabs][Cout][Cin] (same dtype as x), y: channel-minor, dtype `ydtype`.
- * Optional epilogue: y = y * oscale[n*Cout + co] (fp32, per sample & channel), applied before
- * the store; `accumulate` adds into the existing y (fp32 y only). */
+ * Optional fused epilogue (every pointer may be NULL, act 0 / SBG_ACT_LINEAR with gain 1 and clamp < 0 = identity), the
+ * demodulation + noise + bias_act tail of the reference's layers (train_parts/generators.py:84-88,328; ops/bias_act.py:94-123):
+ *   y = clamp( act( acc * oscale[n*Cout + co] + noise[n*noise_stride_n + pixel] + bias[co] ) * gain )
+ * with fp32 oscale / noise / bias, pixel = oy*OW + ox of the launch grid, act in {linear, relu, lrelu}.
+ * `accumulate` adds into the existing y (fp32 y only, no epilogue). */
 #define SBG_MAX_TAPS 16
 typedef struct sbg_conv_params {
     const void* x; const void* w; void* y;
@@ -101,6 +104,8 @@ typedef struct sbg_conv_params {
     int ntaps;
     int tap_dy[SBG_MAX_TAPS], tap_dx[SBG_MAX_TAPS], tap_slab[SBG_MAX_TAPS];
     int accumulate;
+    const float* bias; const float* noise; int64_t noise_stride_n;
+    int act; float alpha, gain, clamp;
 } sbg_conv_params;
 int sbg_conv2d_igemm(const sbg_conv_params* p, sbg_stream_t stream);
 

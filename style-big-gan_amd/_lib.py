@@ -49,6 +49,8 @@ class ConvParams(ctypes.Structure):
         ("stride", ctypes.c_int), ("ntaps", ctypes.c_int),
         ("tap_dy", ctypes.c_int * SBG_MAX_TAPS), ("tap_dx", ctypes.c_int * SBG_MAX_TAPS), ("tap_slab", ctypes.c_int * SBG_MAX_TAPS),
         ("accumulate", ctypes.c_int),
+        ("bias", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("noise_stride_n", ctypes.c_int64),
+        ("act", ctypes.c_int), ("alpha", ctypes.c_float), ("gain", ctypes.c_float), ("clamp", ctypes.c_float),
     ]
 
 

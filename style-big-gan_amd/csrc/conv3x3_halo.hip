@@ -1,23 +1,26 @@
-// conv3x3_halo.hip -- stride-1 KxK (K <= 3) convolution on the matrix cores with halo-staged activations.
+// conv3x3_halo.hip -- 3x3 stride-1 (pad-same) convolution on the matrix cores with halo-staged activations.
 //
-// The dominant convolutions of the StyleGAN2 step (every 3x3 stride-1 layer of G and D, and their data gradients) spend
-// their time, in the generic gather kernel (conv_igemm.hip), moving the same activation bytes L2 -> LDS nine times (once
-// per tap).  Here a workgroup owns a TH x TW patch of output pixels of one image; per 32-channel slice it stages the
-// (TH+2) x (TW+2) input halo ONCE and all nine taps read shifted windows of it straight out of LDS, so the per-tap global
-// traffic is only the 8 KB weight tile:  L2 -> LDS bytes per MFMA clock drop from ~64 B/clk/CU (128x128x32 gather tile)
-// to ~21 B/clk/CU, under the ~56 B/clk/CU the L2 can feed every CU at once.
+// Measured on the gather kernel (conv_igemm.hip, 128 x 128 x 32 tile, LDS-DMA pipeline): with the MFMAs ablated the kernel
+// still takes 87 % of its time, and the DMA stream alone 64 % -- it is bound by L2 -> LDS traffic (16 KB per K-step per
+// workgroup, ~26 B/clk/CU), not by the matrix pipe.  This kernel moves a third of the bytes per flop: a workgroup owns a
+// TH x TW patch of output pixels (256 pixels) of one image; per 32-channel slice the (TH+2) x (TW+2) input halo is staged
+// ONCE and all nine taps read shifted windows of it from LDS, so a K-step (slice, tap) fetches only its 8 KB weight tile
+// plus a ninth of the 22 KB halo.
 //
-// Same contract as sbg_conv2d_igemm restricted to stride 1, |dy|,|dx| <= 1, one image per tile (OH % TH == 0,
-// OW % TW == 0); optional fused prologue / epilogue (see sbg_conv3x3_params in include/sbg_hip.h):
-//   x' = x * iscale[n, ci]                                   (modulation, applied while staging the halo)
-//   y  = act((acc * oscale[n, co] + noise[n, pixel] + bias[co])) * gain, clamped        (demod + noise + bias_act)
+// Same contract as sbg_conv2d_igemm restricted to: stride 1, the nine taps of a 3x3 window (any order, |offset| <= 1),
+// output grid == input grid with H % TH == 0 and W % TW == 0; optional fused epilogue (see sbg_conv3x3_params):
+//   y = clamp(act(acc * oscale[n, co] + noise[n, pixel] + bias[co]) * gain)          (demodulation + noise + bias_act)
+// (`iscale` is not supported by this kernel: modulation is applied to the activations or the weights beforehand.)
 //
-// Workgroup = 256 lanes = 2 (cout) x 2 (pixel) waves; tile 128 cout x 256 pixels; wave tile 64 x 128 (4 x 8 MFMA tiles,
-// 128 accumulator VGPRs).  LDS: halo [2 buffers][4 k-groups][PLANE cells of 16 B] (PLANE = halo pixels rounded up to 16, so
-// every 16-pixel fragment read hits 16 distinct bank slots), weights [2][4][128] cells.  K-step = (channel slice, tap);
-// the next step's weight tile and one sixth of the next slice's halo are issued before the MFMAs of the current step and
-// written to the other buffers after them (issue early / write late), one barrier per step.
+// Workgroup = 256 lanes = 2 (cout) x 2 (pixel) waves, tile 128 cout x 256 pixels, wave tile 64 x 128 (4 x 8 MFMA tiles).
+// Everything is staged by `buffer_load_dwordx4 ... lds`: weights 4 stages deep (3 K-steps in flight; deeper needs a third halo buffer), the next slice's
+// halo in 16-pixel pieces spread over the current slice's last six taps, behind one counted s_waitcnt vmcnt + raw s_barrier per
+// K-step.  Image borders / ragged channels are fetched at an out-of-range buffer offset (hardware returns zeros).
+// LDS images are [row][4 slots of 16 B] written lane-linearly; the k-group -> slot XOR swizzles (weights: (-(row>>2))&3,
+// halo: ((pixel>>2)&1)<<1 -- conflict-free for a 16-pixel fragment at ANY pixel alignment, found by exhaustive search)
+// are applied on the source address and on the fragment reads.
 #include "sbg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -27,46 +30,51 @@ template <> struct Mfma<bf16_mfma> {
     static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
-    static __device__ __forceinline__ float up(unsigned short v) { return bf16_bits_to_f32(v); }
-    static __device__ __forceinline__ unsigned short down(float v) { return f32_to_bf16_bits(v); }
 };
 template <> struct Mfma<f16_mfma> {
     static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
-    static __device__ __forceinline__ float up(unsigned short v) { return f16_bits_to_f32(v); }
-    static __device__ __forceinline__ unsigned short down(float v) { return f32_to_f16_bits(v); }
 };
 
 struct HaloArgs {
     const unsigned short* x; const unsigned short* w; void* y;
-    const float* iscale; const float* oscale; const float* noise; const float* bias;
+    const float* oscale; const float* noise; const float* bias;
     int ydtype;
     int N, H, W, Cin, Cout;
-    int64_t xs_n, xs_h, xs_w, ys_n, ys_h, ys_w, ws_slab, ws_co, noise_sn;
-    int ntaps;
+    int xs_n, xs_h, xs_w;                       // element strides (tensors < 2 GiB)
+    int64_t ys_n, ys_h, ys_w;
+    int ws_slab, ws_co; int64_t noise_sn;
     int tap_dy[9], tap_dx[9], tap_slab[9];
     int act; float alpha, gain, clamp;
     int accumulate;
     int tiles_x, tiles_y, ctiles;
 };
 
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+#define SBG_OOB_OFFSET 0x80000000u
+
 template <class MF, int TH, int TW>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p)
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p, unsigned x_bytes, unsigned w_bytes)
 {
-    constexpr int BC = 128, BP = TH * TW;
+    constexpr int BC = 128, BP = TH * TW, NT = 9;
     static_assert(BP == 256 && (TW % 16) == 0, "256-pixel tile with 16-pixel row segments");
     constexpr int PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
-    constexpr int PLANE = (NPIX + 15) / 16 * 16;            // cells per k-group plane
-    constexpr int HALO_BYTES = 4 * PLANE * 16, WT_BYTES = 4 * BC * 16;
-    constexpr int HL = (NPIX * 4 + 255) / 256;              // halo staging loads per lane per slice
-    constexpr int SEG = TW / 16;                            // 16-pixel segments per tile row
+    constexpr int HPIECES = (NPIX + 15) / 16;               // 16-pixel DMA pieces per halo
+    static_assert(HPIECES <= 6 * 4, "halo pieces must fit taps 0..5 x 4 waves");
+    constexpr int HALO_BYTES = HPIECES * 1024, WT_BYTES = BC * 64;
+    constexpr int NSTAGE = 4, DEPTH = 3, PER_STEP = 3;     // weight stages / K-steps of loads in flight (bytes in flight, not
+                                                            // bandwidth, bound the DMA stream: ~2 us round trip under load);
+                                                            // DMA instructions per wave per K-step: 2 weight + 1 halo / filler
+    constexpr int SEG = TW / 16;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sH = smem;                               // 2 halo buffers
-    unsigned char* sW = smem + 2 * HALO_BYTES;              // 2 weight buffers
+    unsigned char* sW = smem + 2 * HALO_BYTES;              // NSTAGE weight stages
+    unsigned char* sDummy = sW + NSTAGE * WT_BYTES;         // 1 KiB sink for the filler DMA
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
     {   // XCD-aware order: workgroups sharing an XCD (b mod 8) walk neighbouring tiles -> halo rows re-used from that L2
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
@@ -77,129 +85,119 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p)
     const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
     const int c0 = ct * BC, y0 = ty * TH, x0 = tx * TW;
 
-    // ---- staging coordinates --------------------------------------------------------------------------------------
-    const int sg = (tid >> 3) & 3;                                   // k-group of this lane (8 consecutive lanes share it)
-    const int srow = (tid & 7) | ((tid >> 5) << 3);                  // 0..63: row within a 64-row staging pass
-    int64_t h_off[HL]; bool h_ok[HL]; int h_cell[HL];
-#pragma unroll
-    for (int i = 0; i < HL; i++) {
-        const int pp = srow + 64 * i;                                // halo pixel index
-        const int py = pp / PW, px = pp - py * PW;
-        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-        h_ok[i] = pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        h_off[i] = (int64_t)n * p.xs_n + (int64_t)iy * p.xs_h + (int64_t)ix * p.xs_w;
-        h_cell[i] = (pp < NPIX) ? (sg * PLANE + pp) : -1;
-    }
-    int64_t a_off[2]; bool a_ok[2];
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)w_bytes, 0x00020000);
+
+    // ---- DMA lane coordinates: a piece = 16 rows x 4 slots of 16 B; lane -> (row = lane / 4, slot = lane & 3)
+    const int lrow = lane >> 2, lslot = lane & 3;
+    // weights: rows (wave*2 + i)*16 + lrow, source k-group = slot ^ ((-(lrow >> 2)) & 3)
+    const int wg_src = lslot ^ ((-(lrow >> 2)) & 3);
+    unsigned a_base[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        const int co = c0 + srow + 64 * i;
-        a_ok[i] = co < p.Cout;
-        a_off[i] = (int64_t)(a_ok[i] ? co : 0) * p.ws_co;
+        const int co = c0 + (wave * 2 + i) * 16 + lrow;
+        a_base[i] = (co < p.Cout) ? (unsigned)(co * p.ws_co) * 2u : SBG_OOB_OFFSET;
     }
+    // halo piece handled by this wave at tap slot `tp` (tp = 3..8): piece = (tp - 3) * 4 + wave, pixel pp = piece*16 + lrow
+    // source k-group = slot ^ (((pp >> 2) & 1) << 1); byte offset of the pixel (channel 0) or OOB
     const int kchunks = (p.Cin + 31) >> 5;
-    const int nsteps = kchunks * p.ntaps;
+    const int nsteps = kchunks * NT;
 
-    auto load_halo = [&](int chunk, int i) -> short8_t {
-        const int ck = chunk * 32 + sg * 8;
-        short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (h_ok[i] && ck < p.Cin) {
-            v = *reinterpret_cast<const short8_t*>(p.x + h_off[i] + ck);
-            if (p.iscale) {
-                const float* sc = p.iscale + (int64_t)n * p.Cin + ck;
+    auto issue = [&](int step) {
+        const int chunk = step / NT, tp = step - chunk * NT;
+        // -- weights of `step` into stage step % NSTAGE
+        {
+            const int ck = chunk * 32 + wg_src * 8;
+            const unsigned wtap = (unsigned)(p.tap_slab[tp] * p.ws_slab + ck) * 2u;
+            unsigned char* st = sW + (step % NSTAGE) * WT_BYTES;
 #pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = (short)Mfma<MF>::down(Mfma<MF>::up((unsigned short)v[e]) * sc[e]);
+            for (int i = 0; i < 2; i++) {
+                const unsigned okm = 0u - (unsigned)((ck < p.Cin) & (a_base[i] != SBG_OOB_OFFSET));
+                const unsigned off = ((a_base[i] + wtap) & okm) | (SBG_OOB_OFFSET & ~okm);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + (wave * 2 + i) * 1024), 16, off, 0, 0, 0);
             }
         }
-        return v;
-    };
-    auto load_w = [&](int step, short8_t (&r)[2]) {
-        const int chunk = step / p.ntaps, tp = step - chunk * p.ntaps;
-        const int ck = chunk * 32 + sg * 8;
-        const unsigned short* ws = p.w + (int64_t)p.tap_slab[tp] * p.ws_slab + ck;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (a_ok[i] && ck < p.Cin) v = *reinterpret_cast<const short8_t*>(ws + a_off[i]);
-            r[i] = v;
+        // -- one halo piece of slice chunk + 1 (taps 3..8: issued 3 iterations earlier, i.e. while slice `chunk` is already
+        //    being consumed, so the buffer slice chunk - 1 used is free), otherwise a filler: PER_STEP instructions always
+        {
+            const int piece = (tp - 3) * 4 + wave;
+            const bool real = (tp >= 3) && (piece < HPIECES) && (chunk + 1 < kchunks);
+            const int pp = piece * 16 + lrow;
+            const int py = pp / PW, px = pp - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const int ck = (chunk + 1) * 32 + (lslot ^ (((pp >> 2) & 1) << 1)) * 8;
+            const unsigned okm = 0u - (unsigned)(real & (pp < NPIX) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W) & (ck < p.Cin));
+            unsigned off = ((unsigned)(n * p.xs_n + iy * p.xs_h + ix * p.xs_w + ck) * 2u & okm) | (SBG_OOB_OFFSET & ~okm);
+            unsigned char* dst = real ? sH + ((chunk + 1) & 1) * HALO_BYTES + piece * 1024 : sDummy;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, off, 0, 0, 0);
         }
     };
-    auto store_w = [&](int buf, const short8_t (&r)[2]) {
+    // first slice's halo: every wave loads its share up front (pieces wave, wave + 4, ...)
+    auto issue_first_halo = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; i++) *reinterpret_cast<short8_t*>(sW + buf * WT_BYTES + (sg * BC + srow + 64 * i) * 16) = r[i];
+        for (int i = 0; i < 6; i++) {
+            const int piece = i * 4 + wave;
+            const bool real = piece < HPIECES;
+            const int pp = piece * 16 + lrow;
+            const int py = pp / PW, px = pp - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const int ck = (lslot ^ (((pp >> 2) & 1) << 1)) * 8;
+            const unsigned okm = 0u - (unsigned)(real & (pp < NPIX) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W) & (ck < p.Cin));
+            const unsigned off = ((unsigned)(n * p.xs_n + iy * p.xs_h + ix * p.xs_w + ck) * 2u & okm) | (SBG_OOB_OFFSET & ~okm);
+            unsigned char* dst = real ? sH + piece * 1024 : sDummy;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+        }
     };
 
     // ---- MFMA coordinates -------------------------------------------------------------------------------------------
     const int wc = (wave >> 1) * 64;                 // cout offset of this wave
-    const int wseg0 = (wave & 1) * 8;                // first of the wave's eight 16-pixel segments (tile has 16 segments)
+    const int wseg0 = (wave & 1) * 8;                // first of the wave's eight 16-pixel segments
     const int fr = lane & 15, fg = lane >> 4;
+    const int rdA = (fg ^ ((-(fr >> 2)) & 3)) * 16;
     float4_t acc[4][8];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
-    int seg_cell[8];                                 // halo cell of (segment j, lane fr) for tap (0, 0)
+    int seg_pp[8];                                   // halo pixel of (segment j, lane fr) for tap offset (0, 0)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int s = wseg0 + j, r = s / SEG, cseg = (s - r * SEG) * 16;
-        seg_cell[j] = (r + 1) * PW + cseg + fr + 1;
+        seg_pp[j] = (r + 1) * PW + cseg + fr + 1;
     }
 
-    // ---- prologue: slice 0 halo, step 0 weights --------------------------------------------------------------------
-    {
+    issue_first_halo();
 #pragma unroll
-        for (int i = 0; i < HL; i++) {
-            short8_t v = load_halo(0, i);
-            if (h_cell[i] >= 0) *reinterpret_cast<short8_t*>(sH + h_cell[i] * 16) = v;
-        }
-        short8_t rw[2];
-        load_w(0, rw);
-        store_w(0, rw);
-    }
-    __syncthreads();
+    for (int s = 0; s < DEPTH; s++) if (s < nsteps) issue(s);
 
     for (int s = 0; s < nsteps; s++) {
-        const int chunk = s / p.ntaps, tp = s - chunk * p.ntaps;
-        const int hbuf = chunk & 1, wbuf = s & 1;
-        // issue early: next step's weights, and piece `tp` of the next slice's halo
-        short8_t rw[2], rh = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bool more = (s + 1 < nsteps);
-        if (more) load_w(s + 1, rw);
-        const bool halo_piece = (tp < HL) && (chunk + 1 < kchunks);
-        if (halo_piece) {
-#pragma unroll
-            for (int i = 0; i < HL; i++) if (i == tp) rh = load_halo(chunk + 1, i);
+        // this wave's loads of step s have landed once at most (steps issued after s) * PER_STEP remain outstanding
+        const int ahead = (nsteps - 1 - s < DEPTH - 1) ? nsteps - 1 - s : DEPTH - 1;
+        switch (ahead) {
+#define SBG_WAIT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(%0)" :: "n"((k) * PER_STEP) : "memory"); break;
+            SBG_WAIT_CASE(0) SBG_WAIT_CASE(1) SBG_WAIT_CASE(2) SBG_WAIT_CASE(3) SBG_WAIT_CASE(4) SBG_WAIT_CASE(5)
+            SBG_WAIT_CASE(6) SBG_WAIT_CASE(7) SBG_WAIT_CASE(8) SBG_WAIT_CASE(9)
+            default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH - 1) * PER_STEP) : "memory"); break;
+#undef SBG_WAIT_CASE
         }
-        // taps beyond HL-1 never carry a halo piece; with ntaps < HL (1x1 ..) the remaining pieces ride on the last tap
-        // compute
-        const unsigned char* hb = sH + hbuf * HALO_BYTES;
-        const unsigned char* wb = sW + wbuf * WT_BYTES;
+        __builtin_amdgcn_s_barrier();
+        if (s + DEPTH < nsteps) issue(s + DEPTH);
+        const int chunk = s / NT, tp = s - chunk * NT;
+        const unsigned char* hb = sH + (chunk & 1) * HALO_BYTES;
+        const unsigned char* wb = sW + (s % NSTAGE) * WT_BYTES;
         const int shift = p.tap_dy[tp] * PW + p.tap_dx[tp];
         short8_t fa[4], fb[8];
 #pragma unroll
-        for (int i = 0; i < 4; i++) fa[i] = *reinterpret_cast<const short8_t*>(wb + (fg * BC + wc + 16 * i + fr) * 16);
+        for (int i = 0; i < 4; i++) fa[i] = *reinterpret_cast<const short8_t*>(wb + (wc + 16 * i + fr) * 64 + rdA);
 #pragma unroll
-        for (int j = 0; j < 8; j++) fb[j] = *reinterpret_cast<const short8_t*>(hb + (fg * PLANE + seg_cell[j] + shift) * 16);
+        for (int j = 0; j < 8; j++) {
+            const int pp = seg_pp[j] + shift;
+            fb[j] = *reinterpret_cast<const short8_t*>(hb + (pp << 6) + ((fg << 4) ^ ((pp & 4) << 3)));
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[i][j] = Mfma<MF>::run(fa[i], fb[j], acc[i][j]);
-        // write late
-        if (more) store_w(wbuf ^ 1, rw);
-        if (halo_piece) {
-#pragma unroll
-            for (int i = 0; i < HL; i++) if (i == tp && h_cell[i] >= 0) *reinterpret_cast<short8_t*>(sH + (hbuf ^ 1) * HALO_BYTES + h_cell[i] * 16) = rh;
-        }
-        if (tp == p.ntaps - 1 && p.ntaps < HL && chunk + 1 < kchunks) {     // few taps: stage the rest of the next halo now
-            for (int i = p.ntaps; i < HL; i++) {
-                short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int k = 0; k < HL; k++) if (k == i) v = load_halo(chunk + 1, k);
-#pragma unroll
-                for (int k = 0; k < HL; k++) if (k == i && h_cell[k] >= 0) *reinterpret_cast<short8_t*>(sH + (hbuf ^ 1) * HALO_BYTES + h_cell[k] * 16) = v;
-            }
-        }
-        __syncthreads();
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------------------------
@@ -256,22 +254,39 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(HaloArgs p)
 }
 
 template <class MF, int TH, int TW>
-static int launch_halo(HaloArgs& a, hipStream_t stream)
+static int launch_halo(HaloArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
 {
-    constexpr int NPIX = (TH + 2) * (TW + 2), PLANE = (NPIX + 15) / 16 * 16;
-    constexpr int lds = 2 * 4 * PLANE * 16 + 2 * 4 * 128 * 16;
+    constexpr int NPIX = (TH + 2) * (TW + 2), HPIECES = (NPIX + 15) / 16;
+    constexpr int lds = 2 * HPIECES * 1024 + 4 * 128 * 64 + 1024;
     a.tiles_x = a.W / TW; a.tiles_y = a.H / TH; a.ctiles = (a.Cout + 127) / 128;
     const int64_t nblk = (int64_t)a.N * a.tiles_x * a.tiles_y * a.ctiles;
     if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv3x3: grid too large");
     auto kern = conv3x3_halo_kernel<MF, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return sbg_fail(SBG_ERR_LAUNCH, "conv3x3: cannot raise the dynamic LDS limit to %d bytes", lds);
+        attr_set = true;
+    }
     const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
     const double P = (double)a.N * a.H * a.W;
-    SbgProfScope prof(stream, SBG_K_CONV3X3_HALO, 2.0 * P * a.Cout * (double)a.Cin * a.ntaps,
-                      2.0 * P * a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * P * a.Cout * (a.accumulate ? 2 : 1),
-                      {(int)P, a.Cout, a.Cin, a.ntaps, 1, a.H, TH * 1000 + TW});
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    SbgProfScope prof(stream, SBG_K_CONV3X3_HALO, 2.0 * P * a.Cout * (double)a.Cin * 9,
+                      2.0 * P * a.Cin + 2.0 * 9 * a.Cout * (double)a.Cin + ys * P * a.Cout * (a.accumulate ? 2 : 1),
+                      {(int)P, a.Cout, a.Cin, 9, 1, a.H, TH * 1000 + TW});
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
+}
+
+static int64_t x_extent_bytes(const sbg_conv3x3_params* q)
+{
+    return 2 * ((int64_t)(q->N - 1) * q->xs_n + (int64_t)(q->H - 1) * q->xs_h + (int64_t)(q->W - 1) * q->xs_w + q->Cin);
+}
+static int64_t w_extent_bytes(const sbg_conv3x3_params* q)
+{
+    int maxslab = 0;
+    for (int t = 0; t < q->ntaps; t++) if (q->tap_slab[t] > maxslab) maxslab = q->tap_slab[t];
+    return 2 * ((int64_t)maxslab * q->ws_slab + (int64_t)(q->Cout - 1) * q->ws_co + q->Cin);
 }
 
 } // namespace
@@ -279,13 +294,14 @@ static int launch_halo(HaloArgs& a, hipStream_t stream)
 extern "C" int sbg_conv3x3_supported(const sbg_conv3x3_params* q)
 {
     if (!q) return 0;
-    if (q->H % 8 != 0 && q->H % 16 != 0) return 0;
     const bool t32 = (q->W % 32 == 0) && (q->H % 8 == 0);
     const bool t16 = (q->W % 16 == 0) && (q->H % 16 == 0);
     if (!t32 && !t16) return 0;
-    if (q->ntaps < 1 || q->ntaps > 9 || (q->Cin % 8) != 0) return 0;
-    for (int t = 0; t < q->ntaps; t++)
-        if (q->tap_dy[t] < -1 || q->tap_dy[t] > 1 || q->tap_dx[t] < -1 || q->tap_dx[t] > 1) return 0;
+    if (q->ntaps != 9 || (q->Cin % 8) != 0 || q->iscale != nullptr) return 0;
+    for (int t = 0; t < 9; t++)
+        if (q->tap_dy[t] < -1 || q->tap_dy[t] > 1 || q->tap_dx[t] < -1 || q->tap_dx[t] > 1 || q->tap_slab[t] < 0) return 0;
+    if (q->xs_n < 0 || q->xs_h < 0 || q->xs_w < 0 || q->ws_slab < 0 || q->ws_co < 0) return 0;
+    if (x_extent_bytes(q) >= (int64_t)SBG_OOB_OFFSET || w_extent_bytes(q) >= (int64_t)SBG_OOB_OFFSET) return 0;
     return 1;
 }
 
@@ -300,21 +316,20 @@ extern "C" int sbg_conv3x3(const sbg_conv3x3_params* q, sbg_stream_t stream)
     SBG_CHECK((q->xs_n % 8) == 0 && (q->xs_h % 8) == 0 && (q->xs_w % 8) == 0 && (q->ws_slab % 8) == 0 && (q->ws_co % 8) == 0,
               "conv3x3: pixel / row strides must be multiples of 8 elements");
     SBG_CHECK(q->act == SBG_ACT_LINEAR || q->act == SBG_ACT_LRELU || q->act == SBG_ACT_RELU, "conv3x3: fused activation must be linear, relu or lrelu");
-    SBG_CHECK(!q->iscale || sbg_aligned16(q->iscale), "conv3x3: iscale must be 16-byte aligned");
     if (q->N == 0) return SBG_OK;
     HaloArgs a;
     a.x = (const unsigned short*)q->x; a.w = (const unsigned short*)q->w; a.y = q->y;
-    a.iscale = q->iscale; a.oscale = q->oscale; a.noise = q->noise; a.bias = q->bias;
+    a.oscale = q->oscale; a.noise = q->noise; a.bias = q->bias;
     a.ydtype = q->ydtype;
     a.N = q->N; a.H = q->H; a.W = q->W; a.Cin = q->Cin; a.Cout = q->Cout;
-    a.xs_n = q->xs_n; a.xs_h = q->xs_h; a.xs_w = q->xs_w; a.ys_n = q->ys_n; a.ys_h = q->ys_h; a.ys_w = q->ys_w;
-    a.ws_slab = q->ws_slab; a.ws_co = q->ws_co; a.noise_sn = q->noise_stride_n;
-    a.ntaps = q->ntaps;
+    a.xs_n = (int)q->xs_n; a.xs_h = (int)q->xs_h; a.xs_w = (int)q->xs_w; a.ys_n = q->ys_n; a.ys_h = q->ys_h; a.ys_w = q->ys_w;
+    a.ws_slab = (int)q->ws_slab; a.ws_co = (int)q->ws_co; a.noise_sn = q->noise_stride_n;
     for (int t = 0; t < 9; t++) { a.tap_dy[t] = q->tap_dy[t]; a.tap_dx[t] = q->tap_dx[t]; a.tap_slab[t] = q->tap_slab[t]; }
     a.act = q->act; a.alpha = q->alpha; a.gain = q->gain; a.clamp = q->clamp;
     a.accumulate = q->accumulate;
     hipStream_t s = (hipStream_t)stream;
+    const unsigned xb = (unsigned)x_extent_bytes(q), wb = (unsigned)w_extent_bytes(q);
     const bool t32 = (q->W % 32 == 0) && (q->H % 8 == 0);
-    if (q->xdtype == SBG_BF16) return t32 ? launch_halo<bf16_mfma, 8, 32>(a, s) : launch_halo<bf16_mfma, 16, 16>(a, s);
-    return t32 ? launch_halo<f16_mfma, 8, 32>(a, s) : launch_halo<f16_mfma, 16, 16>(a, s);
+    if (q->xdtype == SBG_BF16) return t32 ? launch_halo<bf16_mfma, 8, 32>(a, xb, wb, s) : launch_halo<bf16_mfma, 16, 16>(a, xb, wb, s);
+    return t32 ? launch_halo<f16_mfma, 8, 32>(a, xb, wb, s) : launch_halo<f16_mfma, 16, 16>(a, xb, wb, s);
 }

@@ -40,6 +40,7 @@ template <> struct Mfma<f16_mfma> {
 
 struct ConvArgs {
     const unsigned short* x; const unsigned short* w; void* y; const float* oscale;
+    const float* bias; const float* noise; int64_t noise_sn; int act; float alpha, gain, clamp;
     int ydtype;
     int N, IH, IW, Cin, Cout, OH, OW;
     int64_t xs_n, xs_h, xs_w, ys_n, ys_h, ys_w, ws_slab, ws_co;
@@ -58,23 +59,54 @@ static __device__ __forceinline__ int stage_kgrp(int lane)  { return (lane >> 3)
 template <int TC, int TP>
 static __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, float4_t (&acc)[TC][TP], int c0, int p0, int wc, int wp, int fr, int fg)
 {
+    // per-channel terms depend on the channel tile only: fetch them once (16-B loads when the 4 channels are in range)
+    float4_t bias4[TC];
+    bool full4[TC];
+#pragma unroll
+    for (int i = 0; i < TC; i++) {
+        const int co = c0 + wc + 16 * i + 4 * fg;
+        full4[i] = (co + 4 <= p.Cout);
+        bias4[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (co + e < p.Cout) bias4[i][e] = p.bias[co + e];
+        }
+    }
+    const bool plain = (p.act <= SBG_ACT_LINEAR) && p.gain == 1.f && p.clamp < 0.f && !p.bias && !p.noise && !p.oscale;
 #pragma unroll
     for (int j = 0; j < TP; j++) {
         const int pix = p0 + wp + 16 * j + fr;
         if (pix >= p.P) continue;
         const int ox = pix % p.OW, t = pix / p.OW, oy = t % p.OH, n = t / p.OH;
         const int64_t yoff = (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
+        const float nz = (!plain && p.noise) ? p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox] : 0.f;
 #pragma unroll
         for (int i = 0; i < TC; i++) {
             const int co = c0 + wc + 16 * i + 4 * fg;
             if (co >= p.Cout) continue;
             float4_t v = acc[i][j];
-            if (p.oscale) {
-                const float* sc = p.oscale + (int64_t)n * p.Cout + co;
+            if (!plain) {
+                if (p.oscale) {
+                    const float* sc = p.oscale + (int64_t)n * p.Cout + co;
 #pragma unroll
-                for (int e = 0; e < 4; e++) if (co + e < p.Cout) v[e] *= sc[e];
+                    for (int e = 0; e < 4; e++) if (co + e < p.Cout) v[e] *= sc[e];
+                }
+                v += nz;
+                v += bias4[i];
+                if (p.act == SBG_ACT_LRELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = (v[e] > 0.f) ? v[e] : v[e] * p.alpha;
+                } else if (p.act == SBG_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = (v[e] > 0.f) ? v[e] : 0.f;
+                }
+                v *= p.gain;
+                if (p.clamp >= 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = (v[e] > -p.clamp && v[e] < p.clamp) ? v[e] : (v[e] >= 0.f ? p.clamp : -p.clamp);
+                }
             }
-            const bool full = (co + 4 <= p.Cout);
+            const bool full = full4[i];
             if (p.ydtype == SBG_F32) {
                 float* dst = (float*)p.y + yoff + co;
                 if (full && ((((uintptr_t)dst) & 15) == 0)) {
@@ -246,7 +278,7 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 #define SBG_OOB_OFFSET 0x80000000u      // >= num_records of every descriptor built below (tensors < 2 GiB)
 
 template <class MF, int BC, int BP, int WGC, int WGP, int NSTAGE>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
 {
     static_assert(WGC * WGP == 4, "4 waves per workgroup");
     constexpr int WC = BC / WGC, WP = BP / WGP;
@@ -406,6 +438,7 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     SBG_CHECK(q->ntaps >= 1 && q->ntaps <= SBG_MAX_TAPS, "conv2d_igemm: 1..%d taps", SBG_MAX_TAPS);
     SBG_CHECK(q->stride >= 1, "conv2d_igemm: stride must be >= 1");
     SBG_CHECK(!q->accumulate || q->ydtype == SBG_F32, "conv2d_igemm: accumulate needs an fp32 output");
+    SBG_CHECK(q->act == 0 || q->act == SBG_ACT_LINEAR || q->act == SBG_ACT_RELU || q->act == SBG_ACT_LRELU, "conv2d_igemm: fused activation must be linear, relu or lrelu");
     SBG_CHECK(sbg_aligned16(q->x) && sbg_aligned16(q->w), "conv2d_igemm: x and w must be 16-byte aligned");
     SBG_CHECK((q->xs_n % 8) == 0 && (q->xs_h % 8) == 0 && (q->xs_w % 8) == 0 && (q->ws_slab % 8) == 0 && (q->ws_co % 8) == 0,
               "conv2d_igemm: pixel / row strides must be multiples of 8 elements");
@@ -415,6 +448,8 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
 
     ConvArgs a;
     a.x = (const unsigned short*)q->x; a.w = (const unsigned short*)q->w; a.y = q->y; a.oscale = q->oscale;
+    a.bias = q->bias; a.noise = q->noise; a.noise_sn = q->noise_stride_n;
+    a.act = q->act; a.alpha = q->alpha; a.gain = (q->act == 0 && q->gain == 0.f) ? 1.f : q->gain; a.clamp = (q->act == 0 && q->clamp == 0.f && q->gain == 0.f) ? -1.f : q->clamp;
     a.ydtype = q->ydtype;
     a.N = q->N; a.IH = q->IH; a.IW = q->IW; a.Cin = q->Cin; a.Cout = q->Cout; a.OH = q->OH; a.OW = q->OW;
     a.xs_n = q->xs_n; a.xs_h = q->xs_h; a.xs_w = q->xs_w; a.ys_n = q->ys_n; a.ys_h = q->ys_h; a.ys_w = q->ys_w;

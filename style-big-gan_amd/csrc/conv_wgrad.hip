@@ -360,13 +360,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
     }
 }
 
-static void plan_split(WgradArgs& a, int bca, int bcb)
+static void plan_split_target(WgradArgs& a, int bca, int bcb, int target);
+static void plan_split(WgradArgs& a, int bca, int bcb) { plan_split_target(a, bca, bcb, 1024); }
+static void plan_split_target(WgradArgs& a, int bca, int bcb, int target)
 {
     a.atiles = (a.Ca + bca - 1) / bca;
     a.btiles = (a.Cb + bcb - 1) / bcb;
     a.nchunks = (int)((a.P + 31) / 32);
     const int tiles = a.atiles * a.btiles;
-    int want = (1024 + tiles - 1) / tiles;               // ~4 workgroups per CU
+    int want = (target + tiles - 1) / tiles;             // ~target workgroups in total
     int maxsplit = a.nchunks / 8; if (maxsplit < 1) maxsplit = 1;   // at least 8 chunks of work per workgroup
     if (want > maxsplit) want = maxsplit;
     if (want < 1) want = 1;
@@ -407,6 +409,7 @@ static int fill_args(const sbg_wgrad_params* q, WgradArgs& a)
     a.P = (int64_t)q->N * q->PH * q->PW;
     a.tap0 = 0; a.ntaps_total = q->ntaps;
     if (use_big_tile(q->ntaps)) plan_split(a, 128, 128); else plan_split(a, 64, 64);
+    if (rows_kernel_ok(q, a)) plan_split_target(a, 64, 64, 512);      // one resident workgroup per CU: two waves of workgroups, half the slab traffic
     return SBG_OK;
 }
 

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UpfirdnArgs p)
 // Register-blocked FIR for the hot case: up == down == 1 (the 4x4 low-pass after every transposed / before every strided
 // convolution, and their gradients), channel-minor, 8 channels per lane.  Each lane produces a TY x TX patch of output
 // pixels from a (TY + fh - 1) x (TX + fw - 1) input window held in registers: for the 4x4 filter that is 35 16-B loads per 8
-// outputs (4.4 per output instead of 16), every load 256-B-contiguous across the 16 lanes that share a pixel.
+// outputs (4.4 per output instead of 16; an 8-wide patch measured slower), every load 256-B-contiguous across the 16 lanes that share a pixel.
 #define FIR_TX 4
 #define FIR_TY 2
 #define FIR_MAXF 8

@@ -84,7 +84,33 @@ def _operand_passes(a, b):
     raise RuntimeError(f"conv2d: unsupported dtype {a.dtype}")
 
 
-def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=None, accumulate=False):
+class Epilogue:
+    """fused tail of a convolution launch: y = clamp(act(acc * oscale[n, co] + noise[n, pixel] + bias[co]) * gain)"""
+    __slots__ = ("oscale", "noise", "bias", "act", "alpha", "gain", "clamp", "_keep")
+
+    def __init__(self, oscale=None, noise=None, bias=None, act="linear", alpha=0.0, gain=1.0, clamp=-1.0):
+        assert act in ("linear", "relu", "lrelu")
+        self.oscale, self.noise, self.bias = oscale, noise, bias
+        self.act, self.alpha, self.gain, self.clamp = {"linear": 1, "relu": 2, "lrelu": 3}[act], float(alpha), float(gain), float(clamp)
+        self._keep = []
+
+    def fill(self, p, n, cout, oh, ow):
+        def f32(t, shape):
+            t = t.detach().to(torch.float32).reshape(shape).contiguous()
+            self._keep.append(t)
+            return t
+        if self.oscale is not None:
+            p.oscale = f32(self.oscale, [n, cout]).data_ptr()
+        if self.bias is not None:
+            p.bias = f32(self.bias, [cout]).data_ptr()
+        if self.noise is not None:
+            per_sample = self.noise.numel() != oh * ow
+            nz = f32(self.noise, [n if per_sample else 1, oh * ow])
+            p.noise, p.noise_stride_n = nz.data_ptr(), (oh * ow if per_sample else 0)
+        p.act, p.alpha, p.gain, p.clamp = self.act, self.alpha, self.gain, self.clamp
+
+
+def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=None, accumulate=False, epi=None):
     """x: [N, Cin, IH, IW] channel-minor 16-bit; wp: packed [slabs, Cout, Cin]; y: [N, Cout, YH, YW] channel-minor.
     Writes y[:, :, y_off[0] + y_step[0]*oy, y_off[1] + y_step[1]*ox] for oy < oh, ox < ow."""
     lib = _lib.load()
@@ -106,10 +132,14 @@ def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=N
     for i, (dy, dx, slab) in enumerate(taps):
         p.tap_dy[i], p.tap_dx[i], p.tap_slab[i] = dy, dx, slab
     p.accumulate = int(accumulate)
+    p.act, p.alpha, p.gain, p.clamp = 1, 0.0, 1.0, -1.0
+    if epi is not None:
+        assert not accumulate and y_step == (1, 1)
+        epi.fill(p, n, cout, oh, ow)
     _lib.check(lib.sbg_conv2d_igemm(p, _lib.stream_ptr(x.device)), "sbg_conv2d_igemm")
 
 
-use_halo_kernel = False    # halo-staged stride-1 kernel (csrc/conv3x3_halo.hip): currently slower than the LDS-DMA gather kernel; opt-in
+use_halo_kernel = False     # halo-staged 3x3 kernel (csrc/conv3x3_halo.hip) is opt-in: correct, but slower than the gather kernel so far
 
 
 def _halo_params(x, wp, y, taps, iscale=None, oscale=None, noise=None, bias=None, act=1, alpha=0.0, gain=1.0, clamp=-1.0,
@@ -151,7 +181,7 @@ def _halo_params(x, wp, y, taps, iscale=None, oscale=None, noise=None, bias=None
 
 
 def _halo_ok(x, taps, oh, ow):
-    if not use_halo_kernel or len(taps) > 9 or (oh, ow) != (x.shape[2], x.shape[3]):
+    if not use_halo_kernel or len(taps) != 9 or (oh, ow) != (x.shape[2], x.shape[3]) or x.numel() * 2 >= (1 << 31):
         return False
     if any(abs(dy) > 1 or abs(dx) > 1 for dy, dx, _ in taps):
         return False
@@ -171,8 +201,13 @@ def _launch_groups(taps):
     return [taps[i:i + m] for i in range(0, len(taps), m)]
 
 
-def _conv_forward(x, w, stride, padding):
-    """y[n,co,oy,ox] = sum x[n,ci,oy*s+kh-p,ox*s+kw-p] w[co,ci,kh,kw] (correlation, like F.conv2d)."""
+def epilogue_fusable(x):
+    """the fused epilogue rides on single-pass (16-bit) launches"""
+    return x.dtype in (torch.bfloat16, torch.float16)
+
+
+def _conv_forward(x, w, stride, padding, epi=None):
+    """y[n,co,oy,ox] = sum x[n,ci,oy*s+kh-p,ox*s+kw-p] w[co,ci,kh,kw] (correlation, like F.conv2d); `epi`: fused Epilogue."""
     n, cin, ih, iw = x.shape
     cout, cin_w, kh, kw = w.shape
     assert cin == cin_w and x.dtype == w.dtype
@@ -189,8 +224,9 @@ def _conv_forward(x, w, stride, padding):
     passes = _operand_passes(xp, wpk.contiguous())
     multi = len(passes) > 1 or len(taps) > _lib.SBG_MAX_TAPS
     y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device, memory_format=torch.channels_last)
+    assert epi is None or (not multi)
     first = True
-    halo = sh == 1 and _halo_ok(xp, taps, oh, ow)
+    halo = sh == 1 and epi is None and _halo_ok(xp, taps, oh, ow)
     for xa, wa in passes:
         wa = wa.contiguous()
         if halo:
@@ -198,7 +234,7 @@ def _conv_forward(x, w, stride, padding):
             first = False
             continue
         for grp in _launch_groups(taps):
-            _igemm(xa, wa, y, grp, sh, oh, ow, accumulate=not first)
+            _igemm(xa, wa, y, grp, sh, oh, ow, accumulate=not first, epi=epi)
             first = False
     return y.to(x.dtype) if y.dtype != x.dtype else y
 

@@ -7,22 +7,38 @@ convolution (the weight is flipped first), exactly as in the reference (:29-54).
 """
 import torch
 
+from . import bias_act
 from . import conv2d_gradfix
+from . import conv_bias_act
 from . import upfirdn2d
 from .upfirdn2d import _get_filter_size, _parse_padding
 
 
-def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True):
-    """plain / transposed convolution; flips the taps when a true convolution is requested"""
+def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, tail=None):
+    """plain / transposed convolution; flips the taps when a true convolution is requested.
+    `tail` = dict(b, act, alpha, gain, clamp): the bias_act that follows, fused into the kernel epilogue when possible."""
     if not flip_weight:
         w = w.flip([2, 3])
+    if tail is not None and not transpose and conv_bias_act.fusable(x, w, tail["act"], groups):
+        return conv_bias_act.conv2d_bias_act(x, w, tail["b"], stride=stride, padding=padding, act=tail["act"], alpha=tail["alpha"],
+                                             gain=tail["gain"], clamp=tail["clamp"])
     fn = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
-    return fn(x, w, stride=stride, padding=padding, groups=groups)
+    y = fn(x, w, stride=stride, padding=padding, groups=groups)
+    return _tail(y, tail)
 
 
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
+def _tail(y, tail):
+    if tail is None:
+        return y
+    return bias_act.bias_act(y, tail["b"], act=tail["act"], alpha=tail["alpha"], gain=tail["gain"], clamp=tail["clamp"])
+
+
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, bias_act_tail=None):
     """x: [N, Cin, H, W]; w: [Cout, Cin // groups, kh, kw] (same dtype); f: filter from upfirdn2d.setup_filter().
-    `padding` is relative to the upsampled image.  Returns [N, Cout, H * up // down (+ padding), ...]."""
+    `padding` is relative to the upsampled image.  Returns [N, Cout, H * up // down (+ padding), ...].
+    `bias_act_tail` (extension): dict(b, act, alpha, gain, clamp) -- apply that bias_act to the result, fused into the
+    convolution kernel when the convolution is the last stage."""
+    tail = bias_act_tail
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
@@ -44,15 +60,15 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
 
     if pointwise and down > 1 and up == 1:          # resample on the cheap side of a 1x1 conv: first shrink ...
         x = upfirdn2d.upfirdn2d(x, f, down=down, padding=pad4, flip_filter=flip_filter)
-        return _conv(x, w, groups=groups, flip_weight=flip_weight)
+        return _conv(x, w, groups=groups, flip_weight=flip_weight, tail=tail)
 
     if pointwise and up > 1 and down == 1:          # ... or convolve first, then grow
         x = _conv(x, w, groups=groups, flip_weight=flip_weight)
-        return upfirdn2d.upfirdn2d(x, f, up=up, padding=pad4, gain=up ** 2, flip_filter=flip_filter)
+        return _tail(upfirdn2d.upfirdn2d(x, f, up=up, padding=pad4, gain=up ** 2, flip_filter=flip_filter), tail)
 
     if down > 1 and up == 1:                        # low-pass at full resolution, then a strided convolution
         x = upfirdn2d.upfirdn2d(x, f, padding=pad4, flip_filter=flip_filter)
-        return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight)
+        return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight, tail=tail)
 
     if up > 1:                                      # transposed strided convolution, then low-pass (and optional decimation)
         if groups == 1:
@@ -67,14 +83,14 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         x = upfirdn2d.upfirdn2d(x, f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2, flip_filter=flip_filter)
         if down > 1:
             x = upfirdn2d.upfirdn2d(x, f, down=down, flip_filter=flip_filter)
-        return x
+        return _tail(x, tail)
 
     if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:     # plain convolution with symmetric padding
-        return _conv(x, w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
+        return _conv(x, w, padding=[py0, px0], groups=groups, flip_weight=flip_weight, tail=tail)
 
     # generic composition: pad/crop with an identity FIR, convolve, decimate
     x = upfirdn2d.upfirdn2d(x, (f if up > 1 else None), up=up, padding=pad4, gain=up ** 2, flip_filter=flip_filter)
     x = _conv(x, w, groups=groups, flip_weight=flip_weight)
     if down > 1:
         x = upfirdn2d.upfirdn2d(x, f, down=down, flip_filter=flip_filter)
-    return x
+    return _tail(x, tail)

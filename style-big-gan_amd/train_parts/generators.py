@@ -22,7 +22,7 @@ import torch
 
 from .. import utils
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, modulate, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, conv_bias_act, modulate, upfirdn2d
 
 generators = utils.ClassRegistry()
 
@@ -155,10 +155,11 @@ class Conv2dLayer(torch.nn.Module):
     def forward(self, x, gain=1):
         w = self.weight * self.weight_gain
         b = self.bias.to(x.dtype) if self.bias is not None else None
-        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
-                                            padding=self.padding, flip_weight=(self.up == 1))
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
-        return bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        # conv2d_resample + bias_act (reference :179-184); the bias_act rides in the convolution kernel's epilogue when it can
+        tail = dict(b=b, act=self.activation, alpha=None, gain=self.act_gain * gain, clamp=clamp)
+        return conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                               padding=self.padding, flip_weight=(self.up == 1), bias_act_tail=tail)
 
 
 class MappingNetwork(torch.nn.Module):
@@ -257,9 +258,21 @@ class SynthesisLayer(torch.nn.Module):
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         if self.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        no_grad = not (torch.is_grad_enabled() and (x.requires_grad or styles.requires_grad or self.weight.requires_grad or self.bias.requires_grad))
+        if (no_grad and self.up == 1 and self.activation in ('linear', 'relu', 'lrelu') and x.dtype == torch.bfloat16
+                and conv2d_gradfix.epilogue_fusable(x)):
+            # inference-only pass (e.g. the generator inside the discriminator phases): demodulation, noise, bias, activation,
+            # gain and clamp all ride in the convolution kernel's epilogue -- one read of x*s, one write of y
+            with torch.no_grad():
+                dcoefs = demod_coefficients(self.weight, styles)
+                xs = modulate.scale_nc(x, styles)
+                spec = bias_act.activation_funcs[self.activation]
+                epi = conv2d_gradfix.Epilogue(oscale=dcoefs, noise=noise, bias=self.bias, act=self.activation, alpha=spec.def_alpha,
+                                              gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1))
+                return conv2d_gradfix._conv_forward(xs, self.weight.to(x.dtype), (1, 1), (self.padding, self.padding), epi=epi)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
-        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
 
 
@@ -275,6 +288,10 @@ class ToRGBLayer(torch.nn.Module):
 
     def forward(self, x, w, fused_modconv=True):
         styles = self.affine(w) * self.weight_gain
+        wt = self.weight.to(x.dtype)
+        if conv_bias_act.fusable(x, wt, 'linear'):      # modulation pass, then 1x1 convolution with bias + clamp in its epilogue
+            xs = modulate.scale_nc(x, styles)
+            return conv_bias_act.conv2d_bias_act(xs, wt, self.bias.to(x.dtype), act='linear', clamp=self.conv_clamp)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 

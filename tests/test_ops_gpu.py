@@ -266,3 +266,33 @@ def test_conv3x3_halo_kernel_matches_gather_kernel_and_oracle(dev):
     finally:
         conv2d_gradfix.use_halo_kernel = True
     assert torch.equal(y_halo, y_gather) or rel_err(y_halo, y_gather) < 1e-2    # same math, different summation order
+
+
+def test_fused_conv_bias_act_epilogue(dev):
+    """conv + bias_act in one kernel == the two-op composition (forward, first and second order), incl. strided convs.
+    Small-integer operands make every pre-activation exactly representable in bf16, so both paths see the same activation /
+    clamp masks and must agree to rounding (with random reals a handful of near-zero pre-activations flip sign between the two
+    roundings, which moves individual gradient elements by ~10 % without either path being wrong)."""
+    from style_big_gan_amd.torch_utils.ops import conv_bias_act
+    torch.manual_seed(9)
+    for (stride, pad, act, clamp, gain) in [(1, 1, "lrelu", 40.0, None), (2, 0, "lrelu", None, 0.5), (1, 0, "linear", 6.0, None), (1, 1, "relu", None, None)]:
+        k = 1 if pad == 0 and stride == 1 else 3
+        x = torch.randint(-2, 3, (2, 8, 17, 17), device=dev).to(torch.bfloat16).requires_grad_(True)
+        w = torch.randint(-1, 2, (40, 8, k, k), device=dev).to(torch.bfloat16).requires_grad_(True)
+        b = (torch.randint(-3, 4, (40,), device=dev).float() + 0.5).to(torch.bfloat16).requires_grad_(True)      # never lands on 0
+        y_f = conv_bias_act.conv2d_bias_act(x, w, b, stride=stride, padding=pad, act=act, gain=gain, clamp=clamp)
+        y_u = bias_act.bias_act(conv2d_gradfix.conv2d(x, w, stride=stride, padding=pad), b, act=act, gain=gain, clamp=clamp)
+        assert rel_err(y_f, y_u) < 1e-2
+        dy = torch.randn_like(y_f)
+        gf = torch.autograd.grad((y_f * dy).sum(), [x, w, b], create_graph=True)
+        gu = torch.autograd.grad((y_u * dy).sum(), [x, w, b], create_graph=True)
+        for a_, b_ in zip(gf, gu):
+            assert rel_err(a_, b_) < 2e-2
+        g2f = torch.autograd.grad(gf[0].float().square().sum(), w)[0]     # R1-style second order
+        g2u = torch.autograd.grad(gu[0].float().square().sum(), w)[0]
+        assert rel_err(g2f, g2u) < 3e-2
+    # random reals against the fp32 oracle (forward)
+    xq = torch.randn(2, 16, 8, 8).to(torch.bfloat16).float(); wq = (torch.randn(24, 16, 3, 3) / 12).to(torch.bfloat16).float(); bq = torch.randn(24).to(torch.bfloat16).float()
+    ref = O.bias_act(torch.nn.functional.conv2d(xq, wq, padding=1), bq, act="lrelu", clamp=1.0)
+    got = conv_bias_act.conv2d_bias_act(xq.to(dev, torch.bfloat16), wq.to(dev, torch.bfloat16), bq.to(dev, torch.bfloat16), padding=1, act="lrelu", clamp=1.0)
+    check(got, ref, 2e-2, "fused conv+bias_act vs oracle")
