@@ -110,6 +110,21 @@ class Epilogue:
         p.act, p.alpha, p.gain, p.clamp = self.act, self.alpha, self.gain, self.clamp
 
 
+CONCAT_NUMEL = 1 << 22      # fp32 operands up to this many elements: fold the split passes into ONE launch (see _fold_passes)
+
+
+def _fold_passes(passes, x_cat_dim, w_cat_dim):
+    """[(a_k, b_k)] -> [(cat a_k, cat b_k)]: sum_k conv(a_k, b_k) == conv over the concatenated reduction axis.  For small
+    tensors (the 4x4 / 8x8 fp32 blocks) this turns six launch-bound passes with fp32 read-modify-write outputs into one."""
+    if len(passes) == 1 or passes[0][0].numel() > CONCAT_NUMEL:
+        return passes
+    a = torch.cat([a_ for a_, _ in passes], dim=x_cat_dim)
+    b = torch.cat([b_ for _, b_ in passes], dim=w_cat_dim)
+    if x_cat_dim == 1:
+        a = a.contiguous(memory_format=torch.channels_last)
+    return [(a, b)]
+
+
 def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=None, accumulate=False, epi=None):
     """x: [N, Cin, IH, IW] channel-minor 16-bit; wp: packed [slabs, Cout, Cin]; y: [N, Cout, YH, YW] channel-minor.
     Writes y[:, :, y_off[0] + y_step[0]*oy, y_off[1] + y_step[1]*ox] for oy < oh, ox < ow."""
@@ -221,7 +236,7 @@ def _conv_forward(x, w, stride, padding, epi=None):
     if xp.shape[1] != cin:
         wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
     taps = [(i - ph, j - pw, i * kw + j) for i in range(kh) for j in range(kw)]
-    passes = _operand_passes(xp, wpk.contiguous())
+    passes = _fold_passes(_operand_passes(xp, wpk.contiguous()), 1, 2)
     multi = len(passes) > 1 or len(taps) > _lib.SBG_MAX_TAPS
     y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device, memory_format=torch.channels_last)
     assert epi is None or (not multi)
@@ -254,7 +269,7 @@ def _conv_transpose_forward(x, w, stride, padding, output_padding):
     wpk = w.permute(2, 3, 1, 0).reshape(kh * kw, cout, cin)
     if xp.shape[1] != cin:
         wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
-    passes = _operand_passes(xp, wpk.contiguous())
+    passes = _fold_passes(_operand_passes(xp, wpk.contiguous()), 1, 2)
     # phases: output rows oy = s*o + a use taps kh == (a + p) mod s with input row o + (a + p - kh) / s
     phases = []
     need_zero = False
@@ -298,7 +313,8 @@ def _wgrad(a, b, stride, taps):
     cap, cbp = ap.shape[1], bp.shape[1]
     out = torch.empty([len(taps), cap, cbp], dtype=torch.float32, device=a.device)
     first = True
-    for aa, bb in _operand_passes(ap, bp):
+    for aa, bb in _fold_passes(_operand_passes(ap, bp), 0, 0):
+        aa, bb = _cl(aa), _cl(bb)
         for g0 in range(0, len(taps), _lib.SBG_MAX_TAPS):
             grp = taps[g0:g0 + _lib.SBG_MAX_TAPS]
             p = _lib.WgradParams()
