@@ -277,15 +277,17 @@ static int launch_conv(ConvArgs& a, hipStream_t stream)
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 #define SBG_OOB_OFFSET 0x80000000u      // >= num_records of every descriptor built below (tensors < 2 GiB)
 
-template <class MF, int BC, int BP, int WGC, int WGP, int NSTAGE>
-__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
+template <class MF, int BC, int BP, int WGC, int WGP, int NSTAGE, int MINW>
+__global__ __launch_bounds__(WGC * WGP * 64, MINW) void conv_igemm_dma_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
 {
-    static_assert(WGC * WGP == 4, "4 waves per workgroup");
+    constexpr int NW = WGC * WGP;                      // waves per workgroup (4 or 8)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int WC = BC / WGC, WP = BP / WGP;
     constexpr int TC = WC / 16,  TP = WP / 16;
     constexpr int DEPTH = NSTAGE - 1;
     constexpr int A_BYTES = BC * 64, B_BYTES = BP * 64, STAGE = A_BYTES + B_BYTES;
-    constexpr int IA = BC / 64, IB = BP / 64;          // DMA instructions per wave per stage (16 rows each)
+    static_assert(BC % (16 * NW) == 0 && BP % (16 * NW) == 0, "every wave stages whole 16-row pieces of both operands");
+    constexpr int IA = BC / (16 * NW), IB = BP / (16 * NW);   // DMA instructions per wave per stage (16 rows each)
     constexpr int PER_STEP = IA + IB;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(ConvArgs p, unsi
     conv_epilogue<TC, TP>(p, acc, c0, p0, wc, wp, fr, fg);
 }
 
-template <class MF, int BC, int BP, int WGC, int WGP, int NSTAGE>
+template <class MF, int BC, int BP, int WGC, int WGP, int NSTAGE, int MINW>
 static int launch_conv_dma(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
 {
     a.ptiles = (a.P + BP - 1) / BP;
@@ -391,7 +393,7 @@ static int launch_conv_dma(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipS
     const int64_t nblk = (int64_t)a.ptiles * a.ctiles;
     if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
     constexpr int lds = NSTAGE * (BC * 64 + BP * 64);
-    auto kern = conv_igemm_dma_kernel<MF, BC, BP, WGC, WGP, NSTAGE>;
+    auto kern = conv_igemm_dma_kernel<MF, BC, BP, WGC, WGP, NSTAGE, MINW>;
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -402,7 +404,7 @@ static int launch_conv_dma(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipS
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
                       {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, BC * 1000 + BP});
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, x_bytes, w_bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WGC * WGP * 64), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -416,11 +418,11 @@ static int dispatch_conv(ConvArgs& a, int64_t x_bytes, int64_t w_bytes, bool all
     if (dma) {
         const char* v = getenv("SBG_CONV_TILE");      // experiment switch (tile / pipeline-depth variants)
         const int variant = v ? atoi(v) : 0;
-        if (a.Cout <= 64) return launch_conv_dma<MF, 64, 256, 1, 4, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
-        if (variant == 1) return launch_conv_dma<MF, 128, 256, 2, 2, 3>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
-        if (variant == 2) return launch_conv_dma<MF, 128, 256, 2, 2, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
-        if (variant == 3) return launch_conv_dma<MF, 128, 128, 2, 2, 3>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
-        return launch_conv_dma<MF, 128, 128, 2, 2, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
+        if (a.Cout <= 64) return launch_conv_dma<MF, 64, 256, 1, 4, 4, 1>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
+        if (variant == 1) return launch_conv_dma<MF, 128, 256, 2, 4, 3, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);   // 8 waves, 2 WG/CU
+        if (variant == 2) return launch_conv_dma<MF, 128, 256, 2, 4, 4, 2>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);   // 8 waves, 1 WG/CU
+        if (variant == 3) return launch_conv_dma<MF, 128, 128, 2, 4, 4, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);   // 8 waves, 128^2
+        return launch_conv_dma<MF, 128, 128, 2, 2, 4, 2>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
     }
     if (a.Cout <= 64)  return launch_conv<MF, 64, 256, 1, 4>(a, stream);
     return launch_conv<MF, 128, 128, 2, 2>(a, stream);

@@ -212,15 +212,19 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 #define SBG_OOB_OFFSET 0x80000000u
 
 template <class MF, int S>
-__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsigned a_bytes, unsigned b_bytes)
+__global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsigned a_bytes, unsigned b_bytes)
 {
+    // 8 waves = 2 (ca) x 4 (cb), wave tile 32 x 16 channels for all nine taps (72 accumulator registers): two waves per SIMD
+    // overlap one wave's barrier / transposing LDS reads with the other's MFMAs (the 4-wave version, 144 accumulators, ran at
+    // one wave per SIMD and spent 53 % of its wave cycles waiting).
     // S = stride between the coarse (a) and fine (b) grids: b pixel = S * a pixel + tap, taps = (dy0 + i, dx0 + j), i, j in 0..2
     constexpr int BC = 64, NT = 9, NSTAGE = 3, DEPTH = 2;
     constexpr int PCOLS = S * 31 + 3;                          // b columns needed by a 32-pixel chunk
     constexpr int PPR = (PCOLS + 7) / 8;                       // 8-pixel DMA pieces per patch row
     constexpr int PROW = PPR * 8;                              // patch row pitch in pixels
-    constexpr int NPIECE = ((4 + 3 * PPR + 3) / 4) * 4;        // a-tile (4) + patch pieces, padded to a multiple of 4 with spares
-    constexpr int PIECES = NPIECE / 4;                         // DMA instructions per wave per stage
+    constexpr int NWAVE = 8;
+    constexpr int NPIECE = ((4 + 3 * PPR + NWAVE - 1) / NWAVE) * NWAVE;   // a-tile (4) + patch pieces, padded with spares
+    constexpr int PIECES = NPIECE / NWAVE;                     // DMA instructions per wave per stage
     constexpr int A_BYTES = 32 * 128, STAGE = NPIECE * 1024;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         unsigned char* st = smem + (loc % NSTAGE) * STAGE;
 #pragma unroll
         for (int i = 0; i < PIECES; i++) {
-            const int piece = wave + 4 * i;                    // wave-uniform
+            const int piece = wave + NWAVE * i;                // wave-uniform
             if (piece < 4) {                                   // a-tile rows 8*piece ..
                 const int R = piece * 8 + drow;
                 const int ch = ca0 + src_chunk(R) * 8;
@@ -269,15 +273,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         }
     };
 
-    const int wa = (wave >> 1) * 32, wb = (wave & 1) * 32;
+    const int wa = (wave >> 2) * 32, wb = (wave & 3) * 16;
     const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
-    float4_t acc[NT][2][2];
+    float4_t acc[NT][2][1];
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) acc[t][i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 2; i++) acc[t][i][0] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     // Per-lane LDS byte offsets of the transposing reads, computed once.  The tap order is fixed (t = 3 i + j), so inside the
     // chunk loop every read is `per-lane base (one of 3 column-tap variants) + compile-time constant`.
@@ -287,13 +289,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         const int sw = (((chunk >> 1) ^ ((Rrel >> 1) & 3)) << 1) | (chunk & 1);
         return Rrel * 128 + sw * 16 + (fp & 1) * 8;
     };
-    int offA[2], offB[3][2];
+    int offA[2], offB[3][1];
 #pragma unroll
     for (int i = 0; i < 2; i++) offA[i] = frag_off(4 * fg + fq, wa + 16 * i);
 #pragma unroll
     for (int d = 0; d < 3; d++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) offB[d][j] = frag_off(d + S * (4 * fg + fq), wb + 16 * j);
+        for (int j = 0; j < 1; j++) offB[d][j] = frag_off(d + S * (4 * fg + fq), wb + 16 * j);
     auto read_frag = [&](const unsigned char* base, int off, int hi_off) -> short8_t {
         short4_t lo = lds_tr_read(base + off), hi = lds_tr_read(base + off + hi_off);
         return short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -315,13 +317,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         for (int dyi = 0; dyi < 3; dyi++)
 #pragma unroll
             for (int dxi = 0; dxi < 3; dxi++) {
-                short8_t fb[2];
+                const short8_t fb = read_frag(sP + dyi * PROW * 128, offB[dxi][0], S * 16 * 128);
 #pragma unroll
-                for (int j = 0; j < 2; j++) fb[j] = read_frag(sP + dyi * PROW * 128, offB[dxi][j], S * 16 * 128);
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++) acc[dyi * 3 + dxi][i][j] = Mfma<MF>::run(fa[i], fb[j], acc[dyi * 3 + dxi][i][j]);
+                for (int i = 0; i < 2; i++) acc[dyi * 3 + dxi][i][0] = Mfma<MF>::run(fa[i], fb, acc[dyi * 3 + dxi][i][0]);
             }
     }
 
@@ -334,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradArgs p, unsig
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < 1; j++) {
                 const int cb = cb0 + wb + 16 * j + fi;
                 if (cb >= p.Cb) continue;
 #pragma unroll
@@ -458,7 +456,7 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
     if (rows_kernel_ok(q, a)) {
         const unsigned ab = (unsigned)(2 * ((int64_t)(q->N - 1) * q->as_n + (int64_t)(q->PH - 1) * q->as_h + (int64_t)(q->PW - 1) * q->as_w + q->Ca));
         const unsigned bb = (unsigned)(2 * ((int64_t)(q->N - 1) * q->bs_n + (int64_t)(q->BH - 1) * q->bs_h + (int64_t)(q->BW - 1) * q->bs_w + q->Cb));
-        const int lds = (q->stride == 1) ? 3 * 20 * 1024 : 3 * 32 * 1024;
+        const int lds = (q->stride == 1) ? 3 * 24 * 1024 : 3 * 32 * 1024;
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 1024);
@@ -470,11 +468,11 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
                           {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, 64064});
         const dim3 grid(a.atiles, a.btiles, a.nsplit);
         if (q->stride == 1) {
-            if (bf) hipLaunchKernelGGL((conv_wgrad_rows_kernel<bf16_mfma, 1>), grid, dim3(256), lds, s, a, ab, bb);
-            else    hipLaunchKernelGGL((conv_wgrad_rows_kernel<f16_mfma, 1>), grid, dim3(256), lds, s, a, ab, bb);
+            if (bf) hipLaunchKernelGGL((conv_wgrad_rows_kernel<bf16_mfma, 1>), grid, dim3(512), lds, s, a, ab, bb);
+            else    hipLaunchKernelGGL((conv_wgrad_rows_kernel<f16_mfma, 1>), grid, dim3(512), lds, s, a, ab, bb);
         } else {
-            if (bf) hipLaunchKernelGGL((conv_wgrad_rows_kernel<bf16_mfma, 2>), grid, dim3(256), lds, s, a, ab, bb);
-            else    hipLaunchKernelGGL((conv_wgrad_rows_kernel<f16_mfma, 2>), grid, dim3(256), lds, s, a, ab, bb);
+            if (bf) hipLaunchKernelGGL((conv_wgrad_rows_kernel<bf16_mfma, 2>), grid, dim3(512), lds, s, a, ab, bb);
+            else    hipLaunchKernelGGL((conv_wgrad_rows_kernel<f16_mfma, 2>), grid, dim3(512), lds, s, a, ab, bb);
         }
         SBG_HIP_LAUNCH_CHECK();
     } else if (use_big_tile(a.ntaps)) {
