@@ -31,6 +31,11 @@ if 'conv1' in what:
         cg.use_halo_kernel = halo
         show(f'conv3x3 256 halo={halo}', timed(lambda: cg._conv_forward(x, w, (1, 1), (1, 1)), reps=3, warm=1))
     cg.use_halo_kernel = True
+if 'conv2' in what:
+    for (n, cin, cout, r) in [(32, 128, 128, 256), (32, 512, 512, 64)]:
+        x = torch.randn(n, cin, r, r, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, 3, 3, device=dev) / 30).to(torch.bfloat16)
+        show(f"conv3x3 {n}x{cin}->{cout}@{r}", timed(lambda: cg._conv_forward(x, w, (1, 1), (1, 1))))
 if 'conv' in what:
     for (n, cin, cout, r) in [(32, 128, 128, 256), (32, 256, 256, 128), (32, 512, 512, 64), (32, 512, 512, 32), (32, 512, 512, 16), (32, 512, 512, 8)]:
         x = torch.randn(n, cin, r, r, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)

@@ -1,0 +1,42 @@
+// conv_common.h -- types shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_k64.hip).
+#pragma once
+#include "sbg_common.h"
+
+namespace sbgconv {
+
+struct bf16_mfma { static constexpr int dtype = SBG_BF16; };
+struct f16_mfma  { static constexpr int dtype = SBG_F16;  };
+
+template <class MF> struct Mfma;
+template <> struct Mfma<bf16_mfma> {
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short cvt(float v) { return f32_to_bf16_bits(v); }
+};
+template <> struct Mfma<f16_mfma> {
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short cvt(float v) { return f32_to_f16_bits(v); }
+};
+
+struct ConvArgs {
+    const unsigned short* x; const unsigned short* w; void* y; const float* oscale;
+    const float* bias; const float* noise; int64_t noise_sn; int act; float alpha, gain, clamp;
+    int ydtype;
+    int N, IH, IW, Cin, Cout, OH, OW;
+    int64_t xs_n, xs_h, xs_w, ys_n, ys_h, ys_w, ws_slab, ws_co;
+    int stride, ntaps;
+    int tap_dy[SBG_MAX_TAPS], tap_dx[SBG_MAX_TAPS], tap_slab[SBG_MAX_TAPS];
+    int accumulate;
+    int P;            // N * OH * OW output pixels of this launch
+    int ptiles, ctiles;
+    int debug;        // ablation switches, honoured only by -DSBG_K64_DEBUG builds (diagnosis; see conv_k64.hip)
+};
+
+} // namespace sbgconv
+
+// conv_k64.hip: K-step-64 LDS-DMA kernels (gather and halo-staged).  Returns SBG_OK / an error, or -1 when the launch does not
+// fit these kernels (the caller then uses the kernels of conv_igemm.hip).
+int sbg_conv_k64_dispatch(sbgconv::ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, hipStream_t stream);

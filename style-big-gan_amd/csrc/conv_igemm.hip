@@ -16,40 +16,12 @@
 // LDS image per operand: [k-group g = 0..3][row][8 x 16-bit] (16-B cells).  A ds_read_b128 of MFMA fragments touches 16
 // rows that are distinct mod 16 -> 16 distinct 16-B slots of the 256-B bank row: conflict-free; the staging writes put 8
 // consecutive rows of one k-group in each 8-lane store group: 128 contiguous bytes, conflict-free.
-#include "sbg_common.h"
+#include "conv_common.h"
 #include <cstdlib>
 
+using namespace sbgconv;
+
 namespace {
-
-struct bf16_mfma { static constexpr int dtype = SBG_BF16; };
-struct f16_mfma  { static constexpr int dtype = SBG_F16;  };
-
-template <class MF> struct Mfma;
-template <> struct Mfma<bf16_mfma> {
-    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ unsigned short cvt(float v) { return f32_to_bf16_bits(v); }
-};
-template <> struct Mfma<f16_mfma> {
-    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ unsigned short cvt(float v) { return f32_to_f16_bits(v); }
-};
-
-struct ConvArgs {
-    const unsigned short* x; const unsigned short* w; void* y; const float* oscale;
-    const float* bias; const float* noise; int64_t noise_sn; int act; float alpha, gain, clamp;
-    int ydtype;
-    int N, IH, IW, Cin, Cout, OH, OW;
-    int64_t xs_n, xs_h, xs_w, ys_n, ys_h, ys_w, ws_slab, ws_co;
-    int stride, ntaps;
-    int tap_dy[SBG_MAX_TAPS], tap_dx[SBG_MAX_TAPS], tap_slab[SBG_MAX_TAPS];
-    int accumulate;
-    int P;            // N * OH * OW output pixels of this launch
-    int ptiles, ctiles;
-};
 
 // lane -> (row within a 16-row staging group, k-group): 8 consecutive lanes share a k-group and walk 8 rows.
 static __device__ __forceinline__ int stage_row16(int lane) { return (lane & 7) | ((lane >> 5) << 3); }
@@ -459,13 +431,17 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     a.stride = q->stride; a.ntaps = q->ntaps;
     for (int t = 0; t < SBG_MAX_TAPS; t++) { a.tap_dy[t] = q->tap_dy[t]; a.tap_dx[t] = q->tap_dx[t]; a.tap_slab[t] = q->tap_slab[t]; }
     a.accumulate = q->accumulate;
-    a.P = (int)P; a.ptiles = a.ctiles = 0;
+    a.P = (int)P; a.ptiles = a.ctiles = 0; a.debug = 0;
     hipStream_t s = (hipStream_t)stream;
     int maxslab = 0;
     for (int t = 0; t < q->ntaps; t++) { SBG_CHECK(q->tap_slab[t] >= 0, "conv2d_igemm: negative weight slab"); if (q->tap_slab[t] > maxslab) maxslab = q->tap_slab[t]; }
     const int64_t x_bytes = 2 * ((int64_t)(q->N - 1) * q->xs_n + (int64_t)(q->IH - 1) * q->xs_h + (int64_t)(q->IW - 1) * q->xs_w + q->Cin);
     const int64_t w_bytes = 2 * ((int64_t)maxslab * q->ws_slab + (int64_t)(q->Cout - 1) * q->ws_co + q->Cin);
     const bool allow_dma = getenv("SBG_CONV_NO_DMA") == nullptr && q->xs_n >= 0 && q->xs_h >= 0 && q->xs_w >= 0 && q->ws_slab >= 0 && q->ws_co >= 0;
+    if (allow_dma) {      // K-step-64 kernels (conv_k64.hip) take every launch whose operands fit a 2 GiB buffer descriptor
+        const int rc = sbg_conv_k64_dispatch(a, q->xdtype == SBG_BF16, x_bytes, w_bytes, s);
+        if (rc >= 0) return rc;
+    }
     if (q->xdtype == SBG_BF16) return dispatch_conv<bf16_mfma>(a, x_bytes, w_bytes, allow_dma, s);
     return dispatch_conv<f16_mfma>(a, x_bytes, w_bytes, allow_dma, s);
 }
