@@ -45,11 +45,90 @@ static __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::
 template <int N> static __device__ __forceinline__ void wait_vmcnt_const() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
 // e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
+// Fast path (Cout % 8 == 0, 16-B aligned output rows and per-channel vectors): no per-element guards, branch-free
+// activation (leaky ReLU with alpha 0 / 1 covers ReLU / linear; clamp = med3 with an infinite bound when disabled), one
+// 16-B store per 8 channels.  Everything else takes the guarded element-wise path.
+// Straight-line fast path: the output dtype and "no epilogue math" are template parameters, every 8-channel group of the
+// wave is in range and 16-B aligned (checked by the caller), so the loops below carry no per-element guards and no dtype
+// branches: leaky ReLU with alpha 0 / 1 covers ReLU / linear, clamp = med3 with an infinite bound when disabled.
+template <int TC, int TP, int YDT, bool PLAIN, class PixFn>
+static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix)
+{
+    constexpr int TH2 = TC / 2;
+    const float alpha = (p.act == SBG_ACT_LRELU) ? p.alpha : (p.act == SBG_ACT_RELU ? 0.f : 1.f);
+    const float cl = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+    const float gain = p.gain;
+    float4_t bias_lo[TH2], bias_hi[TH2];
+    if (!PLAIN) {
+#pragma unroll
+        for (int h = 0; h < TH2; h++) {
+            bias_lo[h] = bias_hi[h] = float4_t{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                const float* b = p.bias + cbase + 32 * h + 8 * fg;
+                bias_lo[h] = *reinterpret_cast<const float4_t*>(b);
+                bias_hi[h] = *reinterpret_cast<const float4_t*>(b + 4);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TP; j++) {
+        int n, oy, ox;
+        if (!pix(j, n, oy, ox)) continue;
+        const int64_t yoff = (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
+        float nz = 0.f;
+        if (!PLAIN && p.noise) nz = p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox];
+        const float* sc = p.oscale + (int64_t)n * p.Cout + cbase + 8 * fg;
+#pragma unroll
+        for (int h = 0; h < TH2; h++) {
+            float4_t lo = acc[2 * h][j], hi = acc[2 * h + 1][j];
+            if (!PLAIN) {
+                if (p.oscale) {
+                    lo *= *reinterpret_cast<const float4_t*>(sc + 32 * h);
+                    hi *= *reinterpret_cast<const float4_t*>(sc + 32 * h + 4);
+                }
+                lo += nz + bias_lo[h];
+                hi += nz + bias_hi[h];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float u = lo[e]; u = (u > 0.f) ? u : u * alpha; lo[e] = __builtin_amdgcn_fmed3f(u * gain, -cl, cl);
+                    float w = hi[e]; w = (w > 0.f) ? w : w * alpha; hi[e] = __builtin_amdgcn_fmed3f(w * gain, -cl, cl);
+                }
+            }
+            if (YDT == SBG_F32) {
+                float* dst = (float*)p.y + yoff + 32 * h;
+                if (p.accumulate) { lo += *reinterpret_cast<float4_t*>(dst); hi += *reinterpret_cast<float4_t*>(dst + 4); }
+                *reinterpret_cast<float4_t*>(dst) = lo;
+                *reinterpret_cast<float4_t*>(dst + 4) = hi;
+            } else {
+                short8_t o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { o[e] = (short)f32_to_bf16_bits(lo[e]); o[4 + e] = (short)f32_to_bf16_bits(hi[e]); }
+                *reinterpret_cast<short8_t*>((unsigned short*)p.y + yoff + 32 * h) = o;
+            }
+        }
+    }
+}
+
+// Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
+// e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
 template <int TC, int TP, class PixFn>
 static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix)
 {
     constexpr int TH2 = TC / 2;
     const bool plain = (p.act <= SBG_ACT_LINEAR) && p.gain == 1.f && p.clamp < 0.f && !p.bias && !p.noise && !p.oscale;
+    // fast path: the wave's whole channel range is valid, rows and per-channel vectors 16-B aligned, bf16 / fp32 output
+    const bool fast = (cbase + 16 * TC <= p.Cout) && ((p.Cout & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0) && (((p.ys_n | p.ys_h | p.ys_w) & 7) == 0)
+                      && ((((uintptr_t)p.oscale) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && p.ydtype != SBG_F16;
+    if (fast) {
+        if (p.ydtype == SBG_BF16) {
+            if (plain) conv_epilogue_fast<TC, TP, SBG_BF16, true>(p, acc, cbase, fg, pix);
+            else       conv_epilogue_fast<TC, TP, SBG_BF16, false>(p, acc, cbase, fg, pix);
+        } else {
+            if (plain) conv_epilogue_fast<TC, TP, SBG_F32, true>(p, acc, cbase, fg, pix);
+            else       conv_epilogue_fast<TC, TP, SBG_F32, false>(p, acc, cbase, fg, pix);
+        }
+        return;
+    }
     float bias8[TH2][8];
 #pragma unroll
     for (int h = 0; h < TH2; h++) {
@@ -67,47 +146,26 @@ static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_
         for (int h = 0; h < TH2; h++) {
             const int co = cbase + 32 * h + 8 * fg;
             if (co >= p.Cout) continue;
-            const bool full = (co + 8 <= p.Cout);
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; e++) { v[e] = acc[2 * h][j][e]; v[4 + e] = acc[2 * h + 1][j][e]; }
-            if (!plain) {
-                if (p.oscale) {
-                    const float* sc = p.oscale + (int64_t)n * p.Cout + co;
-#pragma unroll
-                    for (int e = 0; e < 8; e++) if (co + e < p.Cout) v[e] *= sc[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float u = v[e] + nz + bias8[h][e];
+#pragma unroll 1
+            for (int e = 0; e < 8; e++) {            // rolled: this path serves odd channel counts (ToRGB, tails), not the flops
+                if (co + e >= p.Cout) break;
+                float u = v[e];
+                if (!plain) {
+                    if (p.oscale) u *= p.oscale[(int64_t)n * p.Cout + co + e];
+                    u += nz + bias8[h][e];
                     if (p.act == SBG_ACT_LRELU) u = (u > 0.f) ? u : u * p.alpha;
                     else if (p.act == SBG_ACT_RELU) u = (u > 0.f) ? u : 0.f;
                     u *= p.gain;
                     if (p.clamp >= 0.f) u = (u > -p.clamp && u < p.clamp) ? u : (u >= 0.f ? p.clamp : -p.clamp);
-                    v[e] = u;
                 }
-            }
-            if (p.ydtype == SBG_F32) {
-                float* dst = (float*)p.y + yoff + co;
-                if (full && ((((uintptr_t)dst) & 15) == 0)) {
-                    float4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    if (p.accumulate) { o0 += *reinterpret_cast<float4_t*>(dst); o1 += *reinterpret_cast<float4_t*>(dst + 4); }
-                    *reinterpret_cast<float4_t*>(dst) = o0;
-                    *reinterpret_cast<float4_t*>(dst + 4) = o1;
+                if (p.ydtype == SBG_F32) {
+                    float* dst = (float*)p.y + yoff + co + e;
+                    *dst = p.accumulate ? *dst + u : u;
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) if (co + e < p.Cout) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
-                }
-            } else {
-                unsigned short* dst = (unsigned short*)p.y + yoff + co;
-                short8_t o;
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = (short)((p.ydtype == SBG_BF16) ? f32_to_bf16_bits(v[e]) : f32_to_f16_bits(v[e]));
-                if (full && ((((uintptr_t)dst) & 15) == 0)) {
-                    *reinterpret_cast<short8_t*>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) if (co + e < p.Cout) dst[e] = (unsigned short)o[e];
+                    ((unsigned short*)p.y)[yoff + co + e] = (p.ydtype == SBG_BF16) ? f32_to_bf16_bits(u) : f32_to_f16_bits(u);
                 }
             }
         }
@@ -124,7 +182,7 @@ static constexpr int halo_cnt(int t, bool last)
     return IA + ((!last && t >= 3 && (t - 3) * 8 + 7 < HPIECES) ? 1 : 0);
 }
 
-template <class MF, int BC, int BP, int WGC, int WGP, int MODE, int TH, int TW>
+template <class MF, int BC, int BP, int WGC, int WGP, int MODE, int TH, int TW, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
 {
     constexpr int NW = 8;
@@ -218,14 +276,18 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
 #pragma unroll
             for (int i = 0; i < TC; i++) fa[ks][i] = *reinterpret_cast<const short8_t*>(sa + i * 16 * 128 + (frag_off ^ (ks * 64)));
     };
-    auto mma = [&]() {
+    auto mma_half = [&](int ks) {
         if (dbg & 1) return;
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++)
+        for (int i = 0; i < TC; i++)
 #pragma unroll
-            for (int i = 0; i < TC; i++)
+            for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[ks][i], fb[ks][j], acc[i][j]);
+    };
+    auto mma = [&]() { mma_half(0); mma_half(1); };
+    auto read_a_half = [&](int stage, int ks) {
+        const unsigned char* sa = smem + stage * STAGE + wc * 128;
 #pragma unroll
-                for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[ks][i], fb[ks][j], acc[i][j]);
+        for (int i = 0; i < TC; i++) fa[ks][i] = *reinterpret_cast<const short8_t*>(sa + i * 16 * 128 + (frag_off ^ (ks * 64)));
     };
 
     // Ping-pong schedule: waves 0-3 (X) and 4-7 (Y) -- one of each per SIMD -- run half a K-step apart, separated by two
@@ -308,6 +370,17 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
             }
         };
 
+        auto read_b_half = [&](int t, int buf, int ks) {
+            const unsigned char* hb = sH + buf * HALO_BYTES;
+            const int shift = __builtin_amdgcn_readlane(tbl_shift, t);
+#pragma unroll
+            for (int j = 0; j < TP; j++) {
+                const int pp = seg_pp[j] + shift;
+                const int o = pp * 128 + ((fg ^ (pp & 7)) << 4);
+                fb[ks][j] = *reinterpret_cast<const short8_t*>(hb + (o ^ (ks * 64)));
+            }
+        };
+
         int tile = bid;
         TileC cur = decode(tile);
         weight_rows(cur.c0, a_cur);
@@ -329,7 +402,11 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
                 constexpr int t = decltype(tap_tag)::value;
                 if (!grpY) wait_vmcnt_const<halo_cnt<IA, HPIECES>(t + 1, LASTC) + halo_cnt<IA, HPIECES>(t + 2, LASTC)>();
                 __builtin_amdgcn_s_barrier();            // B_a
-                if (!(dbg & 4)) { read_a(stage); read_b(t, par); }
+                if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+                if (!(dbg & 4)) {
+                    if (VAR & 2) { read_a_half(stage, 0); read_b_half(t, par, 0); read_a_half(stage, 1); read_b_half(t, par, 1); }
+                    else { read_a(stage); read_b(t, par); }
+                }
                 if (!(dbg & 2)) {
                     constexpr int ti = (t + LEAD) % NT;
                     const int wst = (stage + LEAD) & (NSTAGE - 1);
@@ -341,10 +418,12 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
                     }
                 }
                 if (grpY) wait_vmcnt_const<halo_cnt<IA, HPIECES>(t + 2, LASTC) + halo_cnt<IA, HPIECES>(t + 3, LASTC)>();
+                if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+                if (VAR & 2) { __builtin_amdgcn_sched_barrier(0); mma_half(0); __builtin_amdgcn_sched_barrier(0); }
                 __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): fragments are in registers, this wave no longer reads the stage
                 __builtin_amdgcn_s_barrier();            // B_b
                 __builtin_amdgcn_sched_barrier(0);
-                mma();
+                if (VAR & 2) mma_half(1); else mma();
                 __builtin_amdgcn_sched_barrier(0);
                 stage = (stage + 1) & (NSTAGE - 1);
             });
@@ -454,7 +533,257 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
     }
 }
 
-template <class MF, int BC, int BP, int WGC, int WGP, int MODE, int TH, int TW>
+// ---------------------------------------------------------------------------------------------------------------------
+// Halo kernel with loader waves.  12 waves: 0-3 (X) and 4-7 (Y) compute in ping-pong as above but issue NO vector-memory
+// instruction inside the K loop; waves 8-9 stream the weight tiles, waves 10-11 the halo.  Why: (1) a compute wave's
+// non-MFMA phase shrinks to `barrier, 16 ds_read_b128, barrier`; (2) vmcnt retires in order, so in the 8-wave kernel a halo
+// piece that misses L2 (537 MB activations do not fit the 256 MB Infinity Cache) stalled the weight stream queued behind it --
+// here the halo loaders have a whole slice (nine K-steps) of lead and the weight loaders never wait for HBM.
+// Every wave executes exactly 2 S + 1 workgroup barriers (S = K-steps of all tiles of this workgroup), index g = 0 .. 2S:
+//   X: B_a(s) = 2s, B_b(s) = 2s + 1, final 2S;   Y: first 0, B_a(s) = 2s + 1, B_b(s) = 2s + 2;
+//   weight loader: per step { wait W(s) landed; 2s; issue W(s + 3) into the stage step s - 1 used (its reads retired before
+//                  2s); 2s + 1 }, final 2S;      halo loader: per slice c { vmcnt(0): halo(c) landed; 18c; issue halo(c + 1) into
+//                  the buffer slice c - 1 used; 18c + 1 .. 18c + 17 }, final 2S.
+template <class MF, int TH, int TW>
+__global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
+{
+    constexpr int BC = 128, BP = 256, WGP = 4;
+    constexpr int WC = 64, WP = 64, TC = 4, TP = 4;
+    static_assert(TH * TW == BP, "halo tile = TH x TW pixels");
+    constexpr int NSTAGE = 4, STAGE = BC * 128;        // weight stages: the loads of step s + 3 are issued while step s computes
+    constexpr int PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
+    constexpr int HPIECES = (NPIX + 7) / 8, HALO_BYTES = HPIECES * 1024;
+    constexpr int NT = 9, SEG = TW / 16;
+    constexpr int WPIECES = BC / 8 / 2;                // weight pieces per weight loader per step
+    constexpr int HPL = (HPIECES + 1) / 2;             // halo pieces per halo loader per slice
+
+#ifdef SBG_K64_DEBUG     // ablations for diagnosis: 1 = no MFMA, 4 = no fragment reads, 8 = no epilogue, 16 = no B_b barrier wait... (timing only)
+    const int dbg = p.debug;
+#else
+    constexpr int dbg = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const sH = smem + NSTAGE * STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {   // XCD-aware tile order: workgroups b and b + 8 share an XCD (L2); give each XCD a contiguous run of tiles
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int tiles_x = p.OW / TW, tiles_y = p.OH / TH;
+    const int ntiles = p.ptiles * p.ctiles, G = gridDim.x;
+    const int my_tiles = (ntiles - bid + G - 1) / G;                  // tiles bid, bid + G, ...  (the grid never exceeds ntiles)
+    const int kchunks = (p.Cin + 63) >> 6;
+    const int nslices = my_tiles * kchunks;                            // slice = one 64-channel slab of one tile = nine K-steps
+    struct TileC { int c0, tn, y0, x0; };
+    auto decode = [&](int tile) -> TileC {
+        TileC r;
+        const int ct_ = tile % p.ctiles; int pt_ = tile / p.ctiles;
+        const int tx = pt_ % tiles_x; pt_ /= tiles_x;
+        const int ty = pt_ % tiles_y;
+        r.c0 = ct_ * BC; r.tn = pt_ / tiles_y; r.y0 = ty * TH; r.x0 = tx * TW;
+        return r;
+    };
+    const int lrow = lane >> 3;
+    const int src_k = ((lane & 7) ^ lrow) * 8;          // DMA lane -> (row = 8 piece + lrow, slot = lane & 7), source k-slot = slot ^ (row & 7)
+
+    if (wave >= 10) {
+        // ---------------------------------------------------------------- halo loader (waves 10, 11) ----------------------
+        const int lh = wave - 10;
+        __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
+        auto issue_halo = [&](const TileC& tc, int chunk, int buf) {
+            const unsigned okc = 0u - (unsigned)(chunk * 64 + src_k < p.Cin);
+            const unsigned img = (unsigned)(tc.tn * (int)p.xs_n + chunk * 64 + src_k) * 2u;
+#pragma unroll 2
+            for (int i = 0; i < HPL; i++) {
+                const int piece = lh * HPL + i;
+                if (piece >= HPIECES) break;
+                const int pp = piece * 8 + lrow;
+                const int py = pp / PW, px = pp - py * PW;
+                const int iy = tc.y0 - 1 + py, ix = tc.x0 - 1 + px;
+                const unsigned okm = okc & (0u - (unsigned)((pp < NPIX) & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW)));
+                const unsigned real = img + (unsigned)(iy * (int)p.xs_h + ix * (int)p.xs_w) * 2u;
+                const unsigned off = (real & okm) | (SBG_OOB_OFFSET & ~okm);      // branch-free: a masked-off lane would leave stale LDS bytes
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(sH + buf * HALO_BYTES + piece * 1024), 16, off, 0, 0, 0);
+            }
+        };
+        int tile = bid, chunk = 0;
+        TileC tc = decode(tile);
+        issue_halo(tc, 0, 0);
+        for (int c = 0; c < nslices; c++) {
+            wait_vmcnt_const<0>();                       // halo(c) has landed
+            __builtin_amdgcn_s_barrier();                // 18c
+            if (c + 1 < nslices && !(dbg & 2)) {
+                if (++chunk == kchunks) { chunk = 0; tile += G; tc = decode(tile); }
+                issue_halo(tc, chunk, (c + 1) & 1);
+            }
+#pragma unroll
+            for (int i = 0; i < 17; i++) __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();                    // 2S
+        return;
+    }
+    if (wave >= 8) {
+        // ---------------------------------------------------------------- weight loader (waves 8, 9) ----------------------
+        const int lw = wave - 8;
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)w_bytes, 0x00020000);
+        const int tl = lane < p.ntaps ? lane : 0;
+        const int tbl_wtap = p.tap_slab[tl] * (int)p.ws_slab * 2;
+        unsigned a_base[WPIECES];
+        auto weight_rows = [&](int c0_) {
+#pragma unroll
+            for (int i = 0; i < WPIECES; i++) {
+                const int co = c0_ + chmap((lw * WPIECES + i) * 8 + lrow);
+                a_base[i] = (co < p.Cout) ? (unsigned)(co * (int)p.ws_co + src_k) * 2u : SBG_OOB_OFFSET;
+            }
+        };
+        // (it, ichunk, itile, istage): coordinates of the step whose weights are issued next
+        int it = 0, ichunk = 0, itile = bid, istage = 0;
+        weight_rows(decode(itile).c0);
+        auto issue_next = [&]() {
+            unsigned char* st = smem + istage * STAGE + lw * WPIECES * 1024;
+            const unsigned kokm = 0u - (unsigned)(ichunk * 64 + src_k < p.Cin);
+            const unsigned wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, it) + ichunk * 128);
+#pragma unroll
+            for (int i = 0; i < WPIECES; i++) {
+                const unsigned okm = kokm & (0u - (unsigned)(a_base[i] != SBG_OOB_OFFSET));
+                const unsigned off = ((a_base[i] + wtap) & okm) | (SBG_OOB_OFFSET & ~okm);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + i * 1024), 16, off, 0, 0, 0);
+            }
+            istage = (istage + 1) & (NSTAGE - 1);
+            if (++it == NT) {
+                it = 0;
+                if (++ichunk == kchunks) { ichunk = 0; itile += G; if (itile < ntiles) weight_rows(decode(itile).c0); }
+            }
+        };
+        const int S = nslices * NT;
+        int issued = 0;                                  // steps issued so far
+        for (; issued < 4 && issued < S; issued++) issue_next();
+        for (int s = 0; s < S; s++) {
+            // W(s) has landed once at most the steps issued after it are outstanding
+            const int newer = issued - 1 - s;            // 0 .. 3
+            if (newer >= 3) wait_vmcnt_const<3 * WPIECES>();
+            else if (newer == 2) wait_vmcnt_const<2 * WPIECES>();
+            else if (newer == 1) wait_vmcnt_const<1 * WPIECES>();
+            else wait_vmcnt_const<0>();
+            __builtin_amdgcn_s_barrier();                // 2s
+            if (s >= 1 && issued < S && !(dbg & 2)) { issue_next(); issued++; }     // step s + 3 -> the stage step s - 1 was read from
+            __builtin_amdgcn_s_barrier();                // 2s + 1
+        }
+        __builtin_amdgcn_s_barrier();                    // 2S
+        return;
+    }
+
+    // -------------------------------------------------------------------- compute waves (0-7) ----------------------------
+    const bool grpY = wave >= 4;
+    const int wci = wave >> 2, wpi = wave & 3;           // waves 0-3 and 4-7 each cover both channel halves? no: wave = wci * 4 + wpi
+    const int wc = wci * WC;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int frag_off = fr * 128 + ((fg ^ (fr & 7)) << 4);          // k-sub 0; k-sub 1 = ^ 64
+    const int tl = lane < p.ntaps ? lane : 0;
+    const int tbl_shift = p.tap_dy[tl] * PW + p.tap_dx[tl];
+    float4_t acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; i++)
+#pragma unroll
+        for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    short8_t fa[2][TC], fb[2][TP];
+    int seg_pp[TP];                                      // patch pixel of (segment j, lane fr) for tap (0, 0)
+#pragma unroll
+    for (int j = 0; j < TP; j++) {
+        const int sg = wpi * TP + j, r = sg / SEG, cseg = (sg - r * SEG) * 16;
+        seg_pp[j] = (r + 1) * PW + cseg + fr + 1;
+    }
+    int stage = 0, par = 0, chunk = 0, tile = bid;
+    TileC cur = decode(tile);
+    if (grpY) __builtin_amdgcn_s_barrier();              // 0
+    for (int c = 0; c < nslices; c++) {
+        const unsigned char* hb = sH + par * HALO_BYTES;
+        static_for<NT>([&](auto tap_tag) {
+            constexpr int t = decltype(tap_tag)::value;
+            const int shift = __builtin_amdgcn_readlane(tbl_shift, t);
+            const unsigned char* sa = smem + stage * STAGE + wc * 128;
+            __builtin_amdgcn_s_barrier();                // B_a: the stage and the halo buffer of this step have landed
+            if (!(dbg & 4)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int i = 0; i < TC; i++) fa[ks][i] = *reinterpret_cast<const short8_t*>(sa + i * 16 * 128 + (frag_off ^ (ks * 64)));
+#pragma unroll
+            for (int j = 0; j < TP; j++) {
+                const int pp = seg_pp[j] + shift;
+                const int o = pp * 128 + ((fg ^ (pp & 7)) << 4);
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) fb[ks][j] = *reinterpret_cast<const short8_t*>(hb + (o ^ (ks * 64)));
+            }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): fragments are in registers, this wave no longer reads the stage
+            __builtin_amdgcn_s_barrier();                // B_b
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 1))
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int i = 0; i < TC; i++)
+#pragma unroll
+                    for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[ks][i], fb[ks][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            stage = (stage + 1) & (NSTAGE - 1);
+        });
+        par ^= 1;
+        if (++chunk < kchunks) continue;
+        if (!(dbg & 8))
+        conv_epilogue8<TC, TP>(p, acc, cur.c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
+            const int sg = wpi * TP + j, r = sg / SEG, cseg = (sg - r * SEG) * 16;
+            n = cur.tn; oy = cur.y0 + r; ox = cur.x0 + cseg + fr;
+            return true;
+        });
+#pragma unroll
+        for (int i = 0; i < TC; i++)
+#pragma unroll
+            for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        chunk = 0; tile += G;
+        if (tile < ntiles) cur = decode(tile);
+    }
+    if (!grpY) __builtin_amdgcn_s_barrier();             // 2S
+}
+
+template <class MF, int TH, int TW>
+static int launch_halo_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
+{
+    constexpr int HPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
+    constexpr int lds = 4 * 128 * 128 + 2 * HPIECES * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    a.ctiles = (a.Cout + 127) / 128;
+    a.ptiles = a.N * (a.OH / TH) * (a.OW / TW);
+    int64_t nblk = (int64_t)a.ptiles * a.ctiles;
+    if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        ncu = n;
+    }
+    if (nblk > ncu) nblk = ncu;     // persistent: one workgroup per CU (the LDS footprint admits no more), each walks tiles b, b + grid, ...
+    auto kern = conv_halo_ld_kernel<MF, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
+        attr_set = true;
+    }
+    const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
+    SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
+                      2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
+                      {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 3128256});
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(768), lds, stream, a, x_bytes, w_bytes);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
+
+template <class MF, int BC, int BP, int WGC, int WGP, int MODE, int TH, int TW, int VAR = 0>
 static int launch_k64(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
 {
     constexpr bool HALO = (MODE == MODE_HALO);
@@ -478,7 +807,7 @@ static int launch_k64(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream
         { const char* e = getenv("SBG_K64_GRID"); if (e && atoi(e) > 0) nblk = atoi(e) < (int64_t)a.ptiles * a.ctiles ? atoi(e) : (int64_t)a.ptiles * a.ctiles; }
 #endif
     }
-    auto kern = conv_k64_kernel<MF, BC, BP, WGC, WGP, MODE, TH, TW>;
+    auto kern = conv_k64_kernel<MF, BC, BP, WGC, WGP, MODE, TH, TW, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -502,7 +831,18 @@ static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStr
     for (int t = 0; halo && t < 9; t++) halo = a.tap_dy[t] >= -1 && a.tap_dy[t] <= 1 && a.tap_dx[t] >= -1 && a.tap_dx[t] <= 1;
     const int64_t tiles256 = (int64_t)((a.P + 255) / 256) * ((a.Cout + 127) / 128);
     if (halo && a.Cout > 64 && tiles256 >= 256) {
-        if (a.OW % 32 == 0 && a.OH % 8 == 0)  return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32>(a, xb, wb, stream);
+        static const char* eld = getenv("SBG_K64_LD");              // 0: 8-wave kernel (every wave loads), default: loader-wave kernel
+        const bool ld = eld ? atoi(eld) != 0 : true;
+        if (ld && a.OW % 32 == 0 && a.OH % 8 == 0)  return launch_halo_ld<MF, 8, 32>(a, xb, wb, stream);
+        if (ld && a.OW % 16 == 0 && a.OH % 16 == 0) return launch_halo_ld<MF, 16, 16>(a, xb, wb, stream);
+        if (a.OW % 32 == 0 && a.OH % 8 == 0) {
+            static const char* ev = getenv("SBG_K64_VAR");          // schedule experiments
+            const int var = ev ? atoi(ev) : 0;
+            if (var == 1) return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32, 1>(a, xb, wb, stream);
+            if (var == 2) return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32, 2>(a, xb, wb, stream);
+            if (var == 3) return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32, 3>(a, xb, wb, stream);
+            return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32>(a, xb, wb, stream);
+        }
         if (a.OW % 16 == 0 && a.OH % 16 == 0) return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 16, 16>(a, xb, wb, stream);
     }
     if (a.Cout <= 64) return launch_k64<MF, 64, 256, 1, 8, MODE_GATHER, 16, 16>(a, xb, wb, stream);
