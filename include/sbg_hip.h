@@ -90,7 +90,9 @@ int sbg_upfirdn2d(const sbg_upfirdn2d_params* p, sbg_stream_t stream);
  * demodulation + noise + bias_act tail of the reference's layers (train_parts/generators.py:84-88,328; ops/bias_act.py:94-123):
  *   y = clamp( act( acc * oscale[n*Cout + co] + noise[n*noise_stride_n + pixel] + bias[co] ) * gain )
  * with fp32 oscale / noise / bias, pixel = oy*OW + ox of the launch grid, act in {linear, relu, lrelu}.
- * `accumulate` adds into the existing y (fp32 y only, no epilogue). */
+ * `accumulate` adds into the existing y (fp32 y only, no epilogue).
+ * Kernel choice is internal (csrc/conv_k64.hip): stride-1 launches with the nine taps of a 3x3 window on a tile-aligned grid
+ * take the persistent halo-staged kernel, everything else the gather (im2col-on-the-fly) kernel. */
 #define SBG_MAX_TAPS 16
 typedef struct sbg_conv_params {
     const void* x; const void* w; void* y;
@@ -109,35 +111,6 @@ typedef struct sbg_conv_params {
 } sbg_conv_params;
 int sbg_conv2d_igemm(const sbg_conv_params* p, sbg_stream_t stream);
 
-
-/* ------------------------------------------------------------------------------------------
- * Stride-1 convolution with |tap offsets| <= 1 (3x3 / 1x3 / 3x1 / 1x1 pad-same, and the data gradient of such) with the
- * input halo staged once per channel slice -- the fast path for the layers that dominate the StyleGAN2 step -- plus the
- * fused modulation prologue and demodulation / noise / bias / activation epilogue of
- * `modulated_conv2d` + `bias_act` (train_parts/generators.py:79-88,328; torch_utils/ops/bias_act.py:94-123):
- *
- *   y[n,oy,ox,co] = clamp( act( oscale[n,co] * sum_t sum_ci (x[n,oy+dy_t,ox+dx_t,ci] * iscale[n,ci]) * w[slab_t][co][ci]
- *                               + noise[n*noise_stride_n + oy*W + ox] + bias[co] ) * gain )
- *
- * iscale / oscale / noise / bias are optional fp32 arrays (NULL = absent); act in {linear, relu, lrelu}; clamp < 0 disables.
- * Output grid == input grid (H x W).  sbg_conv3x3_supported() tells whether the shape fits the tiling (H, W multiples of
- * (8, 32) or (16, 16), Cin % 8 == 0); otherwise use sbg_conv2d_igemm. */
-typedef struct sbg_conv3x3_params {
-    const void* x; const void* w; void* y;
-    const float* iscale; const float* oscale; const float* noise; const float* bias;
-    int xdtype, ydtype;
-    int N, H, W, Cin, Cout;
-    int64_t xs_n, xs_h, xs_w;
-    int64_t ys_n, ys_h, ys_w;
-    int64_t ws_slab, ws_co;
-    int64_t noise_stride_n;
-    int ntaps;
-    int tap_dy[9], tap_dx[9], tap_slab[9];
-    int act; float alpha, gain, clamp;
-    int accumulate;
-} sbg_conv3x3_params;
-int sbg_conv3x3_supported(const sbg_conv3x3_params* p);
-int sbg_conv3x3(const sbg_conv3x3_params* p, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight gradient (replaces `aten::cudnn_convolution_backward_weight` /
@@ -213,7 +186,7 @@ int sbg_attention_fwd(const float* theta, const float* phi, const float* g, floa
  * (or the number pending when out == NULL). */
 enum sbg_kernel_kind {
     SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
-    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_CONV3X3_HALO = 8, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10
 };
 typedef struct sbg_prof_record {
     int    kind;            /* enum sbg_kernel_kind */

@@ -54,22 +54,6 @@ class ConvParams(ctypes.Structure):
     ]
 
 
-class Conv3x3Params(ctypes.Structure):
-    _fields_ = [
-        ("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p),
-        ("iscale", ctypes.c_void_p), ("oscale", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("bias", ctypes.c_void_p),
-        ("xdtype", ctypes.c_int), ("ydtype", ctypes.c_int),
-        ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
-        ("xs_n", ctypes.c_int64), ("xs_h", ctypes.c_int64), ("xs_w", ctypes.c_int64),
-        ("ys_n", ctypes.c_int64), ("ys_h", ctypes.c_int64), ("ys_w", ctypes.c_int64),
-        ("ws_slab", ctypes.c_int64), ("ws_co", ctypes.c_int64), ("noise_stride_n", ctypes.c_int64),
-        ("ntaps", ctypes.c_int),
-        ("tap_dy", ctypes.c_int * 9), ("tap_dx", ctypes.c_int * 9), ("tap_slab", ctypes.c_int * 9),
-        ("act", ctypes.c_int), ("alpha", ctypes.c_float), ("gain", ctypes.c_float), ("clamp", ctypes.c_float),
-        ("accumulate", ctypes.c_int),
-    ]
-
-
 class WgradParams(ctypes.Structure):
     _fields_ = [
         ("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("out", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
@@ -89,7 +73,7 @@ class ProfRecord(ctypes.Structure):
                 ("ms", ctypes.c_float), ("pad", ctypes.c_int)]
 
 
-KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 8: "conv3x3_halo", 9: "sn_power", 10: "attention"}
+KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 9: "sn_power", 10: "attention"}
 
 _lib = None
 _lock = threading.Lock()
@@ -103,8 +87,6 @@ SYMBOLS = [
                                                    _c.c_int64, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
     ("sbg_conv2d_igemm", _c.c_int, [_c.POINTER(ConvParams), _c.c_void_p]),
-    ("sbg_conv3x3_supported", _c.c_int, [_c.POINTER(Conv3x3Params)]),
-    ("sbg_conv3x3", _c.c_int, [_c.POINTER(Conv3x3Params), _c.c_void_p]),
     ("sbg_conv2d_wgrad_workspace", _c.c_int64, [_c.POINTER(WgradParams)]),
     ("sbg_conv2d_wgrad", _c.c_int, [_c.POINTER(WgradParams), _c.c_void_p]),
     ("sbg_scale_nc", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_void_p]),

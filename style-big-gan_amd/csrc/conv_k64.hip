@@ -1,23 +1,24 @@
-// conv_k64.hip -- implicit-GEMM convolution, K-step 64, 8 waves (two per SIMD), LDS-DMA staging in full 128-B lines.
+// conv_k64.hip -- implicit-GEMM convolution on the gfx950 matrix cores, K-step 64, LDS-DMA staging in full 128-B lines.
 //
 // Same launch contract as conv_igemm.hip (tap list, see include/sbg_hip.h); this file holds the kernels that carry the
-// flops of the StyleGAN2 step.  What changed against the 128 x 128 x 32 kernel, and why (rocprofv3):
-//   * that kernel was bound by the L2 -> LDS stream, not by the matrix pipe: 16 KB per K-step per workgroup in 64-B row
-//     pieces (half a cache line per request).  Here a K-step is 64 channels deep, so every staged row is one whole 128-B
-//     line (8 rows x 128 B per wave instruction), and the tile is 128 output channels x 256 pixels: 0.75x the bytes per
-//     flop at half the requests per byte.
-//   * HALO mode (3x3 / stride 1 / output grid == input grid): a workgroup owns a TH x TW patch of one image; per
+// flops of the StyleGAN2 step.  Design points (measured with rocprofv3 / ablation builds):
+//   * The 128 x 128 x 32 kernel of conv_igemm.hip was bound by the L2 -> LDS stream (64-B row pieces = half a cache line
+//     per request, 15.6 B per kflop).  Here a K-step is 64 channels deep, so every staged row is one whole 128-B line
+//     (8 rows x 128 B per wave instruction) and the tile is 128 output channels x 256 pixels.
+//   * conv_halo_ld_kernel (3x3 / stride 1 / output grid == input grid): a workgroup owns a TH x TW patch of one image; per
 //     64-channel slice the (TH + 2) x (TW + 2) input halo is staged ONCE and all nine taps read shifted windows of it, so
-//     a K-step fetches its 16 KB weight tile plus a ninth of the 43 KB halo: 5 B per kflop instead of 15.6.
-//   * 8 waves = 2 per SIMD, and the fragments of K-step s + 1 are read from LDS into a second register set while the
-//     MFMAs of step s issue, so LDS latency, DMA issue and the barrier hide behind the matrix pipe.
-//   * output channels are permuted inside each 32-channel block so that a lane ends up with 8 CONSECUTIVE channels of a
-//     pixel: the epilogue stores 16 B (bf16) per lane instead of 8.
+//     a K-step fetches its 16 KB weight tile plus a ninth of the 43 KB halo: 5 B per kflop.  Persistent (one workgroup
+//     per CU walks its tiles, the pipeline runs through tile boundaries) with dedicated loader waves.
+//   * conv_k64_kernel (everything else: strided, transposed phases, 1x1): im2col on the fly, every wave stages its share.
+//   * Compute waves run as two groups in ping-pong (one wave of each per SIMD): while one group reads its MFMA fragments
+//     from LDS the other owns the matrix pipe; per-step control flow is compile-time (unrolled taps) or two-way scalar.
+//   * Output channels are permuted inside each 32-channel block so that a lane ends up with 8 CONSECUTIVE channels of a
+//     pixel: the epilogue stores 16 B (bf16) per lane, straight-line code specialised on dtype / fused tail.
 //
 // LDS images are [row][8 slots x 16 B] (128 B per row = 64 channels of one tap), written lane-linearly by
 // `buffer_load_dwordx4 ... lds` (lane -> row = lane >> 3, slot = lane & 7).  The k-slot -> slot XOR swizzle
 // slot = kslot ^ (row & 7) is applied on the SOURCE address and on the fragment reads: ds_read_b128 of 16 consecutive
-// rows is conflict-free at any row alignment (scratch/swz_check.py), which the shifted halo windows need.
+// rows is conflict-free at any row alignment (SQ_LDS_BANK_CONFLICT = 0 measured), which the shifted halo windows need.
 #include "conv_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -29,8 +30,6 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 #define SBG_OOB_OFFSET 0x80000000u      // >= num_records of every descriptor built below (tensors < 2 GiB): reads as zeros
-
-enum { MODE_GATHER = 0, MODE_HALO = 1 };
 
 // LDS row R of the weight tile holds output channel c0 + chmap(R): inside a 32-row block, MFMA row m of the even / odd
 // 16-row tile maps to channel 8 (m / 4) + 4 (tile & 1) + (m % 4), so accumulator tiles (2h, 2h + 1) of a lane hold
@@ -172,38 +171,20 @@ static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_
     }
 }
 
-// DMA instructions every wave issues together with the weights of the step whose tap index is t (t >= 9: a step of the
-// next slice; `last`: there is no next slice).  Halo pieces ride in tap slots 3..8 (see HFIRST); the final slot is only
-// partly populated (piece index >= HPIECES for some waves), so it counts as zero: a vmcnt count may be too SMALL, never too large.
-template <int IA, int HPIECES>
-static constexpr int halo_cnt(int t, bool last)
-{
-    if (t >= 9) return last ? 0 : IA;
-    return IA + ((!last && t >= 3 && (t - 3) * 8 + 7 < HPIECES) ? 1 : 0);
-}
-
-template <class MF, int BC, int BP, int WGC, int WGP, int MODE, int TH, int TW, int VAR = 0>
+// Gather (im2col-on-the-fly) kernel: any tap list and stride; one 128 (or 64) x 256 (or 128) tile per workgroup, 8 waves.
+template <class MF, int BC, int BP, int WGC, int WGP>
 __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
 {
     constexpr int NW = 8;
     static_assert(WGC * WGP == NW, "8 waves per workgroup");
-    constexpr bool HALO = (MODE == MODE_HALO);
     constexpr int WC = BC / WGC, WP = BP / WGP;        // wave tile
     constexpr int TC = WC / 16,  TP = WP / 16;         // 16 x 16 MFMA tiles per wave
     static_assert(WC % 32 == 0 && WP % 16 == 0 && BC % 64 == 0 && BP % 64 == 0, "tile shape");
-    static_assert(!HALO || TH * TW == BP, "halo tile = TH x TW pixels");
     constexpr int IA = BC / 64;                        // weight pieces (8 rows x 128 B) per wave per K-step
-    constexpr int IB = HALO ? 0 : BP / 64;             // gathered pixel pieces per wave per K-step
-    constexpr int NSTAGE = HALO ? 4 : 3;               // LDS stages; the loads of step s + NSTAGE - 1 are issued in step s
+    constexpr int IB = BP / 64;                        // gathered pixel pieces per wave per K-step
+    constexpr int NSTAGE = 3;                          // LDS stages; the loads of step s + NSTAGE - 1 are issued in step s
     constexpr int LEAD = NSTAGE - 1;
-    constexpr int A_BYTES = BC * 128, B_BYTES = HALO ? 0 : BP * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
-    constexpr int HPIECES = (NPIX + 7) / 8, HALO_BYTES = HPIECES * 1024;
-    constexpr int HSLOTS = (HPIECES + NW - 1) / NW;    // halo pieces per wave and slice
-    constexpr int NT = 9, SEG = TW / 16;
-    // A halo piece of slice c + 1 refills the buffer slice c - 1 was read from; it is issued with the weights of step
-    // (c, t), i.e. LEAD steps before that step, which must lie behind the last read of slice c - 1: t >= LEAD.
-    static_assert(!HALO || (LEAD == 3 && HSLOTS <= NT - LEAD), "halo pieces ride in tap slots LEAD .. 8");
+    constexpr int A_BYTES = BC * 128, B_BYTES = BP * 128, STAGE = A_BYTES + B_BYTES;
 
 #ifdef SBG_K64_DEBUG     // ablations for diagnosis: 1 = no MFMA, 2 = no DMA inside the K loop, 4 = no fragment reads, 8 = no epilogue
     const int dbg = p.debug;
@@ -211,7 +192,6 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
     constexpr int dbg = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const sH = smem + NSTAGE * STAGE;   // HALO: two halo buffers behind the weight stages
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -221,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int c0 = (bid % p.ctiles) * BC, p0 = (bid / p.ctiles) * BP;     // gather mode: one tile per workgroup
+    const int c0 = (bid % p.ctiles) * BC, p0 = (bid / p.ctiles) * BP;     // one tile per workgroup
 
     __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)w_bytes, 0x00020000);
@@ -240,7 +220,6 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
     // per-tap constants live in lane t of a VGPR and are fetched with v_readlane (no scalar-memory latency inside the K loop)
     const int tl = lane < p.ntaps ? lane : 0;
     const int tbl_dy = p.tap_dy[tl], tbl_dx = p.tap_dx[tl];
-    const int tbl_shift = tbl_dy * PW + tbl_dx;
     const int tbl_wtap = p.tap_slab[tl] * (int)p.ws_slab * 2;
 
     // weights of (tap t, slice chunk) -> stage `stage`
@@ -276,18 +255,14 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
 #pragma unroll
             for (int i = 0; i < TC; i++) fa[ks][i] = *reinterpret_cast<const short8_t*>(sa + i * 16 * 128 + (frag_off ^ (ks * 64)));
     };
-    auto mma_half = [&](int ks) {
+    auto mma = [&]() {
         if (dbg & 1) return;
 #pragma unroll
-        for (int i = 0; i < TC; i++)
+        for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[ks][i], fb[ks][j], acc[i][j]);
-    };
-    auto mma = [&]() { mma_half(0); mma_half(1); };
-    auto read_a_half = [&](int stage, int ks) {
-        const unsigned char* sa = smem + stage * STAGE + wc * 128;
+            for (int i = 0; i < TC; i++)
 #pragma unroll
-        for (int i = 0; i < TC; i++) fa[ks][i] = *reinterpret_cast<const short8_t*>(sa + i * 16 * 128 + (frag_off ^ (ks * 64)));
+                for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[ks][i], fb[ks][j], acc[i][j]);
     };
 
     // Ping-pong schedule: waves 0-3 (X) and 4-7 (Y) -- one of each per SIMD -- run half a K-step apart, separated by two
@@ -299,168 +274,7 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
     //        step s + NSTAGE, issued behind B_a(s + 1) >= 2s + 2.
     // Everything that decides a vmcnt count is a compile-time constant (unrolled taps) or a two-way scalar branch.
 
-    if constexpr (HALO) {
-        // Persistent: a workgroup walks tiles bid, bid + G, ... and the K-step pipeline runs straight through tile boundaries, so
-        // the next tile's halo and first weights are in flight while this tile's epilogue stores issue.  A "slice" is one
-        // 64-channel slab of one tile (nine steps); slices alternate between the two halo buffers (`par`).
-        struct TileC { int c0, tn, y0, x0; };
-        const int tiles_x = p.OW / TW, tiles_y = p.OH / TH;
-        const int ntiles = p.ptiles * p.ctiles, G = gridDim.x;
-        auto decode = [&](int tile) -> TileC {
-            TileC r;
-            const int ct_ = tile % p.ctiles; int pt_ = tile / p.ctiles;
-            const int tx = pt_ % tiles_x; pt_ /= tiles_x;
-            const int ty = pt_ % tiles_y;
-            r.c0 = ct_ * BC; r.tn = pt_ / tiles_y; r.y0 = ty * TH; r.x0 = tx * TW;
-            return r;
-        };
-        auto weight_rows = [&](int c0_, unsigned (&ab)[IA]) {
-#pragma unroll
-            for (int i = 0; i < IA; i++) {
-                const int co = c0_ + chmap((wave * IA + i) * 8 + lrow);
-                ab[i] = (co < p.Cout) ? (unsigned)(co * (int)p.ws_co + src_k) * 2u : SBG_OOB_OFFSET;
-            }
-        };
-        // halo piece q * 8 + wave, lane's pixel: byte offset of (pixel, src_k) in the image, or out of range -- the same for every slice of a tile
-        auto halo_offsets = [&](const TileC& tc, unsigned (&ho)[HSLOTS]) {
-#pragma unroll
-            for (int q = 0; q < HSLOTS; q++) {
-                const int pp = (q * NW + wave) * 8 + lrow;
-                const int py = pp / PW, px = pp - py * PW;
-                const int iy = tc.y0 - 1 + py, ix = tc.x0 - 1 + px;
-                const bool ok = (pp < NPIX) & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
-                ho[q] = ok ? (unsigned)(tc.tn * (int)p.xs_n + iy * (int)p.xs_h + ix * (int)p.xs_w + src_k) * 2u : SBG_OOB_OFFSET;
-            }
-        };
-        unsigned a_cur[IA], a_nxt[IA], hoff[HSLOTS];   // weight rows of the tile being computed / of the next slice's tile; halo offsets of the next slice's tile
-        auto issue_wt = [&](const unsigned (&ab)[IA], int t, int chunk, int stage) {      // weights of (tap t, slice chunk) -> stage
-            unsigned char* st = smem + stage * STAGE;
-            const bool kok = chunk * 64 + src_k < p.Cin;
-            const unsigned wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, t) + chunk * 128);
-#pragma unroll
-            for (int i = 0; i < IA; i++) {
-                const unsigned okm = 0u - (unsigned)(kok & (ab[i] != SBG_OOB_OFFSET));
-                const unsigned off = ((ab[i] + wtap) & okm) | (SBG_OOB_OFFSET & ~okm);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + (wave * IA + i) * 1024), 16, off, 0, 0, 0);
-            }
-        };
-        auto issue_h = [&](int q, int chunk, int buf) {  // piece q * 8 + wave of a slice (channels chunk * 64 ..) -> halo buffer buf
-            const int piece = q * NW + wave;
-            if (piece < HPIECES) {
-                const unsigned okm = 0u - (unsigned)(chunk * 64 + src_k < p.Cin);        // branch-free, as above
-                const unsigned off = ((hoff[q] + (unsigned)chunk * 128u) & okm) | (SBG_OOB_OFFSET & ~okm);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(sH + buf * HALO_BYTES + piece * 1024), 16, off, 0, 0, 0);
-            }
-        };
-        int seg_pp[TP];                                  // patch pixel of (segment j, lane fr) for tap (0, 0)
-#pragma unroll
-        for (int j = 0; j < TP; j++) {
-            const int sg = wpi * TP + j, r = sg / SEG, cseg = (sg - r * SEG) * 16;
-            seg_pp[j] = (r + 1) * PW + cseg + fr + 1;
-        }
-        auto read_b = [&](int t, int buf) {
-            const unsigned char* hb = sH + buf * HALO_BYTES;
-            const int shift = __builtin_amdgcn_readlane(tbl_shift, t);
-#pragma unroll
-            for (int j = 0; j < TP; j++) {
-                const int pp = seg_pp[j] + shift;
-                const int o = pp * 128 + ((fg ^ (pp & 7)) << 4);
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++) fb[ks][j] = *reinterpret_cast<const short8_t*>(hb + (o ^ (ks * 64)));
-            }
-        };
-
-        auto read_b_half = [&](int t, int buf, int ks) {
-            const unsigned char* hb = sH + buf * HALO_BYTES;
-            const int shift = __builtin_amdgcn_readlane(tbl_shift, t);
-#pragma unroll
-            for (int j = 0; j < TP; j++) {
-                const int pp = seg_pp[j] + shift;
-                const int o = pp * 128 + ((fg ^ (pp & 7)) << 4);
-                fb[ks][j] = *reinterpret_cast<const short8_t*>(hb + (o ^ (ks * 64)));
-            }
-        };
-
-        int tile = bid;
-        TileC cur = decode(tile);
-        weight_rows(cur.c0, a_cur);
-#pragma unroll
-        for (int i = 0; i < IA; i++) a_nxt[i] = a_cur[i];
-        halo_offsets(cur, hoff);
-        // prologue: halo of the first slice, weights of steps 0 .. LEAD - 1
-#pragma unroll
-        for (int q = 0; q < HSLOTS; q++) issue_h(q, 0, 0);
-#pragma unroll
-        for (int t = 0; t < LEAD; t++) issue_wt(a_cur, t, 0, t);
-        wait_vmcnt_const<2 * IA>();                      // step 0 (steps 1 and 2 may be in flight; no halo piece rides with them)
-        if (grpY) __builtin_amdgcn_s_barrier();
-        int stage = 0, par = 0, chunk = 0;               // weight stage of the step being computed, halo buffer and channel slab of the slice
-        // nine steps of one slice; `nchunk` = channel slab of the next slice (LASTC: there is no next slice)
-        auto slice = [&](int nchunk, auto last_tag) {
-            constexpr bool LASTC = decltype(last_tag)::value;
-            static_for<NT>([&](auto tap_tag) {
-                constexpr int t = decltype(tap_tag)::value;
-                if (!grpY) wait_vmcnt_const<halo_cnt<IA, HPIECES>(t + 1, LASTC) + halo_cnt<IA, HPIECES>(t + 2, LASTC)>();
-                __builtin_amdgcn_s_barrier();            // B_a
-                if (VAR & 1) __builtin_amdgcn_s_setprio(1);
-                if (!(dbg & 4)) {
-                    if (VAR & 2) { read_a_half(stage, 0); read_b_half(t, par, 0); read_a_half(stage, 1); read_b_half(t, par, 1); }
-                    else { read_a(stage); read_b(t, par); }
-                }
-                if (!(dbg & 2)) {
-                    constexpr int ti = (t + LEAD) % NT;
-                    const int wst = (stage + LEAD) & (NSTAGE - 1);
-                    if (t + LEAD < NT) {
-                        issue_wt(a_cur, ti, chunk, wst);
-                        if (!LASTC && ti - LEAD < HSLOTS) issue_h(ti - LEAD, nchunk, par ^ 1);
-                    } else if (!LASTC) {
-                        issue_wt(a_nxt, ti, nchunk, wst);
-                    }
-                }
-                if (grpY) wait_vmcnt_const<halo_cnt<IA, HPIECES>(t + 2, LASTC) + halo_cnt<IA, HPIECES>(t + 3, LASTC)>();
-                if (VAR & 1) __builtin_amdgcn_s_setprio(0);
-                if (VAR & 2) { __builtin_amdgcn_sched_barrier(0); mma_half(0); __builtin_amdgcn_sched_barrier(0); }
-                __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): fragments are in registers, this wave no longer reads the stage
-                __builtin_amdgcn_s_barrier();            // B_b
-                __builtin_amdgcn_sched_barrier(0);
-                if (VAR & 2) mma_half(1); else mma();
-                __builtin_amdgcn_sched_barrier(0);
-                stage = (stage + 1) & (NSTAGE - 1);
-            });
-        };
-        while (true) {
-            const bool last_chunk = chunk + 1 == kchunks;
-            const int ntile = tile + G;
-            const bool last_slice = last_chunk && ntile >= ntiles;
-            TileC nxt = cur;
-            if (last_chunk && !last_slice) {             // the next slice opens the next tile: its weight rows and halo offsets
-                nxt = decode(ntile);
-                weight_rows(nxt.c0, a_nxt);
-                halo_offsets(nxt, hoff);
-            }
-            if (last_slice) slice(0, std::true_type{});
-            else            slice(last_chunk ? 0 : chunk + 1, std::false_type{});
-            par ^= 1;
-            if (!last_chunk) { chunk++; continue; }
-            if (!(dbg & 8)) {
-                conv_epilogue8<TC, TP>(p, acc, cur.c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
-                    const int sg = wpi * TP + j, r = sg / SEG, cseg = (sg - r * SEG) * 16;
-                    n = cur.tn; oy = cur.y0 + r; ox = cur.x0 + cseg + fr;
-                    return true;
-                });
-            }
-            if (last_slice) break;
-#pragma unroll
-            for (int i = 0; i < TC; i++)
-#pragma unroll
-                for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
-            tile = ntile; cur = nxt; chunk = 0;
-#pragma unroll
-            for (int i = 0; i < IA; i++) a_cur[i] = a_nxt[i];
-        }
-        if (!grpY) __builtin_amdgcn_s_barrier();
-        return;
-    } else {
+    {
         int b_iy0[IB], b_ix0[IB]; unsigned b_base[IB];
 #pragma unroll
         for (int i = 0; i < IB; i++) {
@@ -521,16 +335,14 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
         if (!grpY) __builtin_amdgcn_s_barrier();
     }
 
-    // ---- epilogue (gather mode) -------------------------------------------------------------------------------------
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
     if (dbg & 8) return;
-    if constexpr (!HALO) {
-        conv_epilogue8<TC, TP>(p, acc, c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
-            const int pix = p0 + wp + 16 * j + fr;
-            const int pp = pix < p.P ? pix : 0;
-            ox = pp % p.OW; const int t = pp / p.OW; oy = t % p.OH; n = t / p.OH;
-            return pix < p.P;
-        });
-    }
+    conv_epilogue8<TC, TP>(p, acc, c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
+        const int pix = p0 + wp + 16 * j + fr;
+        const int pp = pix < p.P ? pix : 0;
+        ox = pp % p.OW; const int t = pp / p.OW; oy = t % p.OH; n = t / p.OH;
+        return pix < p.P;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -783,31 +595,16 @@ static int launch_halo_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipSt
     return SBG_OK;
 }
 
-template <class MF, int BC, int BP, int WGC, int WGP, int MODE, int TH, int TW, int VAR = 0>
+template <class MF, int BC, int BP, int WGC, int WGP>
 static int launch_k64(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
 {
-    constexpr bool HALO = (MODE == MODE_HALO);
-    constexpr int NSTAGE = HALO ? 4 : 3;
-    constexpr int HPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
-    constexpr int lds = NSTAGE * (BC * 128 + (HALO ? 0 : BP * 128)) + (HALO ? 2 * HPIECES * 1024 : 0);
+    constexpr int lds = 3 * (BC * 128 + BP * 128);
     static_assert(lds <= 160 * 1024, "LDS budget");
     a.ctiles = (a.Cout + BC - 1) / BC;
-    a.ptiles = HALO ? a.N * (a.OH / TH) * (a.OW / TW) : (a.P + BP - 1) / BP;
-    int64_t nblk = (int64_t)a.ptiles * a.ctiles;
+    a.ptiles = (a.P + BP - 1) / BP;
+    const int64_t nblk = (int64_t)a.ptiles * a.ctiles;
     if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
-    if (HALO) {             // persistent: one workgroup per CU (the LDS footprint admits no more), each walks tiles b, b + grid, ...
-        static int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-            ncu = n;
-        }
-        if (nblk > ncu) nblk = ncu;
-#ifdef SBG_K64_DEBUG
-        { const char* e = getenv("SBG_K64_GRID"); if (e && atoi(e) > 0) nblk = atoi(e) < (int64_t)a.ptiles * a.ctiles ? atoi(e) : (int64_t)a.ptiles * a.ctiles; }
-#endif
-    }
-    auto kern = conv_k64_kernel<MF, BC, BP, WGC, WGP, MODE, TH, TW, VAR>;
+    auto kern = conv_k64_kernel<MF, BC, BP, WGC, WGP>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -817,7 +614,7 @@ static int launch_k64(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream
     const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
-                      {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, (HALO ? 2000000 : 1000000) + BC * 1000 + BP});
+                      {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 1000000 + BC * 1000 + BP});
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
@@ -826,28 +623,17 @@ static int launch_k64(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream
 template <class MF>
 static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStream_t stream)
 {
-    // halo mode: stride 1, nine taps with |offset| <= 1, output grid == input grid, tile-aligned
+    // halo kernel: stride 1, nine taps with |offset| <= 1, output grid == input grid, tile-aligned, enough tiles to fill the chip
     bool halo = level >= 2 && a.stride == 1 && a.ntaps == 9 && a.OH == a.IH && a.OW == a.IW;
     for (int t = 0; halo && t < 9; t++) halo = a.tap_dy[t] >= -1 && a.tap_dy[t] <= 1 && a.tap_dx[t] >= -1 && a.tap_dx[t] <= 1;
     const int64_t tiles256 = (int64_t)((a.P + 255) / 256) * ((a.Cout + 127) / 128);
     if (halo && a.Cout > 64 && tiles256 >= 256) {
-        static const char* eld = getenv("SBG_K64_LD");              // 0: 8-wave kernel (every wave loads), default: loader-wave kernel
-        const bool ld = eld ? atoi(eld) != 0 : true;
-        if (ld && a.OW % 32 == 0 && a.OH % 8 == 0)  return launch_halo_ld<MF, 8, 32>(a, xb, wb, stream);
-        if (ld && a.OW % 16 == 0 && a.OH % 16 == 0) return launch_halo_ld<MF, 16, 16>(a, xb, wb, stream);
-        if (a.OW % 32 == 0 && a.OH % 8 == 0) {
-            static const char* ev = getenv("SBG_K64_VAR");          // schedule experiments
-            const int var = ev ? atoi(ev) : 0;
-            if (var == 1) return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32, 1>(a, xb, wb, stream);
-            if (var == 2) return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32, 2>(a, xb, wb, stream);
-            if (var == 3) return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32, 3>(a, xb, wb, stream);
-            return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 8, 32>(a, xb, wb, stream);
-        }
-        if (a.OW % 16 == 0 && a.OH % 16 == 0) return launch_k64<MF, 128, 256, 2, 4, MODE_HALO, 16, 16>(a, xb, wb, stream);
+        if (a.OW % 32 == 0 && a.OH % 8 == 0)  return launch_halo_ld<MF, 8, 32>(a, xb, wb, stream);
+        if (a.OW % 16 == 0 && a.OH % 16 == 0) return launch_halo_ld<MF, 16, 16>(a, xb, wb, stream);
     }
-    if (a.Cout <= 64) return launch_k64<MF, 64, 256, 1, 8, MODE_GATHER, 16, 16>(a, xb, wb, stream);
-    if (tiles256 < 256) return launch_k64<MF, 128, 128, 2, 4, MODE_GATHER, 16, 16>(a, xb, wb, stream);
-    return launch_k64<MF, 128, 256, 2, 4, MODE_GATHER, 16, 16>(a, xb, wb, stream);
+    if (a.Cout <= 64) return launch_k64<MF, 64, 256, 1, 8>(a, xb, wb, stream);
+    if (tiles256 < 256) return launch_k64<MF, 128, 128, 2, 4>(a, xb, wb, stream);
+    return launch_k64<MF, 128, 256, 2, 4>(a, xb, wb, stream);
 }
 
 } // namespace

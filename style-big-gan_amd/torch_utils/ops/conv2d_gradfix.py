@@ -5,7 +5,7 @@ Host-side mirror of ``stylegan2ada/torch_utils/ops/conv2d_gradfix.py``: same pub
 autograd structure (:107-165): the data gradient of a convolution is the opposite (transposed / plain)
 convolution, the weight gradient is its own Function whose backward is again made of convolutions, so R1 and
 path-length double-backward work.  Where the reference calls cuDNN, this module launches the hand-written
-implicit-GEMM kernels ``sbg_conv2d_igemm`` / ``sbg_conv2d_wgrad`` (csrc/conv_igemm.hip, csrc/conv_wgrad.hip).
+implicit-GEMM kernels ``sbg_conv2d_igemm`` / ``sbg_conv2d_wgrad`` (csrc/conv_igemm.hip, csrc/conv_k64.hip, csrc/conv_wgrad.hip).
 
 Layout / precision: activations are processed channel-minor (``torch.channels_last``; other layouts are converted),
 bf16 / f16 tensors take one MFMA pass with fp32 accumulation; fp32 tensors are split into three bf16 parts (hi + mid + lo =
@@ -154,62 +154,6 @@ def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=N
     _lib.check(lib.sbg_conv2d_igemm(p, _lib.stream_ptr(x.device)), "sbg_conv2d_igemm")
 
 
-use_halo_kernel = False     # halo-staged 3x3 kernel (csrc/conv3x3_halo.hip) is opt-in: correct, but slower than the gather kernel so far
-
-
-def _halo_params(x, wp, y, taps, iscale=None, oscale=None, noise=None, bias=None, act=1, alpha=0.0, gain=1.0, clamp=-1.0,
-                 accumulate=False):
-    """fill an sbg_conv3x3_params (output grid == input grid); returns (params, keepalive)"""
-    p = _lib.Conv3x3Params()
-    n, cin, ih, iw = x.shape
-    keep = []
-
-    def f32(t):
-        if t is None:
-            return None
-        t = t.to(torch.float32).contiguous()
-        keep.append(t)
-        return t.data_ptr()
-
-    p.x, p.w, p.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
-    p.iscale, p.oscale, p.bias = f32(iscale), f32(oscale), f32(bias)
-    p.noise = None
-    p.noise_stride_n = 0
-    if noise is not None:
-        nz = noise.to(torch.float32)
-        nz = nz.reshape(1, ih * iw) if nz.numel() == ih * iw else nz.reshape(n, ih * iw)
-        nz = nz.contiguous()
-        keep.append(nz)
-        p.noise = nz.data_ptr()
-        p.noise_stride_n = 0 if nz.shape[0] == 1 else ih * iw
-    p.xdtype, p.ydtype = _lib.dtype_code(x.dtype), _lib.dtype_code(y.dtype)
-    p.N, p.H, p.W, p.Cin, p.Cout = n, ih, iw, cin, wp.shape[1]
-    p.xs_n, p.xs_h, p.xs_w = x.stride(0), x.stride(2), x.stride(3)
-    p.ys_n, p.ys_h, p.ys_w = y.stride(0), y.stride(2), y.stride(3)
-    p.ws_slab, p.ws_co = wp.stride(0), wp.stride(1)
-    p.ntaps = len(taps)
-    for i, (dy, dx, slab) in enumerate(taps):
-        p.tap_dy[i], p.tap_dx[i], p.tap_slab[i] = dy, dx, slab
-    p.act, p.alpha, p.gain, p.clamp = int(act), float(alpha), float(gain), float(clamp)
-    p.accumulate = int(accumulate)
-    return p, keep
-
-
-def _halo_ok(x, taps, oh, ow):
-    if not use_halo_kernel or len(taps) != 9 or (oh, ow) != (x.shape[2], x.shape[3]) or x.numel() * 2 >= (1 << 31):
-        return False
-    if any(abs(dy) > 1 or abs(dx) > 1 for dy, dx, _ in taps):
-        return False
-    h, w = x.shape[2], x.shape[3]
-    return (w % 32 == 0 and h % 8 == 0) or (w % 16 == 0 and h % 16 == 0)
-
-
-def _halo(x, wp, y, taps, **kw):
-    lib = _lib.load()
-    p, keep = _halo_params(x, wp, y, taps, **kw)
-    _lib.check(lib.sbg_conv3x3(p, _lib.stream_ptr(x.device)), "sbg_conv3x3")
-
-
 def _launch_groups(taps):
     """split a tap list into launches of at most SBG_MAX_TAPS taps"""
     m = _lib.SBG_MAX_TAPS
@@ -241,13 +185,8 @@ def _conv_forward(x, w, stride, padding, epi=None):
     y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device, memory_format=torch.channels_last)
     assert epi is None or (not multi)
     first = True
-    halo = sh == 1 and epi is None and _halo_ok(xp, taps, oh, ow)
     for xa, wa in passes:
         wa = wa.contiguous()
-        if halo:
-            _halo(xa, wa, y, taps, accumulate=not first)
-            first = False
-            continue
         for grp in _launch_groups(taps):
             _igemm(xa, wa, y, grp, sh, oh, ow, accumulate=not first, epi=epi)
             first = False
@@ -290,13 +229,8 @@ def _conv_transpose_forward(x, w, stride, padding, output_padding):
     if need_zero:
         y.zero_()
     first = True
-    halo = s == 1 and len(phases) == 1 and _halo_ok(xp, phases[0][4], oh, ow)
     for xa, wa in passes:
         wa = wa.contiguous()
-        if halo:
-            _halo(xa, wa, y, phases[0][4], accumulate=not first)
-            first = False
-            continue
         for a, b, goh, gow, taps in phases:
             for gi, grp in enumerate(_launch_groups(taps)):
                 _igemm(xa, wa, y, grp, 1, goh, gow, y_off=(a, b), y_step=(s, s), accumulate=(not first) or gi > 0)

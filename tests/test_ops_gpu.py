@@ -249,23 +249,26 @@ def test_fma(dev):
         check(u, v, 1e-5)
 
 
-def test_conv3x3_halo_kernel_matches_gather_kernel_and_oracle(dev):
-    """shapes that take the halo-staged kernel (W % 32 == 0 and H % 8 == 0, or 16-multiples), incl. ragged channel counts"""
-    for dtype in [torch.bfloat16, torch.float32]:
-        for (n, cin, cout, h, w, k) in [(2, 32, 128, 8, 32, 3), (1, 40, 72, 16, 32, 3), (2, 136, 200, 16, 16, 3), (3, 64, 64, 32, 64, 3),
-                                        (2, 16, 24, 16, 16, 1), (1, 8, 130, 8, 64, 3)]:
-            _conv_case(dev, dtype, n, cin, cout, h, w, k, 1, k // 2, False)
+def test_conv_k64_halo_and_gather_kernels(dev):
+    """shapes large enough (>= 256 tiles of 128 x 256) to take the persistent halo-staged kernels of csrc/conv_k64.hip
+    -- (8, 32) patches with W % 32 == 0, (16, 16) patches otherwise -- and the 128 x 256 gather kernel, with ragged channel counts
+    (Cin % 64 != 0, Cout % 128 != 0) and more tiles than workgroups; fp32 goes through the split passes with an accumulating epilogue."""
+    _conv_case(dev, torch.bfloat16, 4, 72, 136, 64, 128, 3, 1, 1, False)       # halo (8, 32), 2 channel tiles, K tail
+    _conv_case(dev, torch.bfloat16, 36, 64, 128, 48, 48, 3, 1, 1, False)       # halo (16, 16)
+    _conv_case(dev, torch.bfloat16, 3, 128, 128, 160, 160, 3, 1, 1, False)     # 300 tiles on 256 workgroups: ragged last round
+    _conv_case(dev, torch.float32, 2, 16, 128, 128, 256, 3, 1, 1, False)       # fp32: six bf16 passes, accumulate
+    _conv_case(dev, torch.bfloat16, 2, 40, 200, 129, 257, 3, 2, 0, False)      # gather 128 x 256, stride 2 -> 64 x 128
+    _conv_case(dev, torch.bfloat16, 2, 72, 40, 128, 128, 3, 2, 0, True)        # transposed: four gather launches -> 257 x 257
+    # fused epilogue on the halo kernel vs the fp32 oracle composition
     torch.manual_seed(8)
-    x = torch.randn(2, 64, 16, 32, device=dev, dtype=torch.bfloat16)
-    w = (torch.randn(96, 64, 3, 3, device=dev) / 24).to(torch.bfloat16)
-    conv2d_gradfix.use_halo_kernel = True
-    y_halo = conv2d_gradfix.conv2d(x, w, padding=1)
-    conv2d_gradfix.use_halo_kernel = False
-    try:
-        y_gather = conv2d_gradfix.conv2d(x, w, padding=1)
-    finally:
-        conv2d_gradfix.use_halo_kernel = True
-    assert torch.equal(y_halo, y_gather) or rel_err(y_halo, y_gather) < 1e-2    # same math, different summation order
+    n, cin, cout, r = 4, 64, 128, 128
+    xq = torch.randn(n, cin, r, r).to(torch.bfloat16).float(); wq = (torch.randn(cout, cin, 3, 3) / 24).to(torch.bfloat16).float()
+    osc = torch.rand(n, cout) + 0.5; noise = torch.randn(n, 1, r, r); bias = torch.randn(cout)
+    ref = torch.nn.functional.conv2d(xq, wq, padding=1) * osc[:, :, None, None] + noise
+    ref = O.bias_act(ref, bias, act="lrelu", gain=1.2, clamp=1.5)
+    epi = conv2d_gradfix.Epilogue(oscale=osc.to(dev), noise=noise.to(dev), bias=bias.to(dev), act="lrelu", alpha=0.2, gain=1.2, clamp=1.5)
+    got = conv2d_gradfix._conv_forward(xq.to(dev, torch.bfloat16), wq.to(dev, torch.bfloat16), (1, 1), (1, 1), epi=epi)
+    check(got, ref, 2e-2, "halo kernel fused epilogue vs oracle")
 
 
 def test_fused_conv_bias_act_epilogue(dev):
