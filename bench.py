@@ -63,6 +63,31 @@ def summarize_kernels(records):
     return out
 
 
+# kernel kind of the launch log -> kernel names in the rocprofv3 traces
+PMC_KERNELS = {'conv_igemm': ('conv_halo_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel'),
+               'conv_wgrad': ('conv_wgrad_rows_kernel', 'conv_wgrad_kernel'), 'upfirdn2d': ('upfirdn2d_fir_kernel', 'upfirdn2d_kernel'),
+               'bias_act': ('bias_act',), 'scale_nc': ('scale_nc',), 'dot_hw': ('dot_hw',)}
+
+
+def pmc_traffic(kind):
+    """HBM bytes per launch of `kind` from the newest profiles/*_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of separate
+    rocprofv3 --pmc passes over this same bench command (profiles/collect.sh; PMC counters cannot be read from inside the
+    process).  Returns (bytes_per_launch, source) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')), key=os.path.getmtime)
+    if not files:
+        return None, None
+    try:
+        data = json.load(open(files[-1]))['kernels']
+    except Exception:
+        return None, None
+    tot = n = 0
+    for name in PMC_KERNELS.get(kind, ()):
+        if name in data and data[name]['launches'] > 0:
+            tot += data[name]['hbm_bytes_per_launch'] * data[name]['launches']; n += data[name]['launches']
+    return (round(tot / n), os.path.relpath(files[-1], ROOT)) if n else (None, None)
+
+
 def cpu_baseline(sample_batch=2, res=RES):
     """One Gmain + Dmain + Dreg pass of the CPU oracle on `sample_batch` images at the benchmark's shapes (fp32, all host
     threads); returns img/s of a G+D step with Dreg amortised over 4 iterations, like the GPU figure."""
@@ -173,6 +198,11 @@ def main():
                 roofline = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                                 frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                                 launches=k['launches'], avg_launch_ms=round(k['ms'] / k['launches'], 4))
+        if roofline is not None:
+            roofline['traffic'], src = pmc_traffic(dom)
+            if src:
+                roofline['traffic_source'] = src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch averaged over the same launches)'
+                roofline['algorithmic_bytes_per_launch'] = round(kern[dom]['bytes'] / kern[dom]['launches'])
         # the 256x256 modulated 3x3 conv (M = N*65536 pixels, Cout 128, K = 9*128): the kernel the 40 % MFMA target names
         tgt = [r for r in records if r['kind'] == 'conv_igemm' and r['dims'][1] == 128 and r['dims'][2] == 128 and r['dims'][3] == 9
                and r['dims'][0] == args.batch_gpu * args.res * args.res]

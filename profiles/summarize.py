@@ -1,0 +1,49 @@
+"""Condense the rocprofv3 passes of profiles/collect.sh into the files committed under profiles/:
+   <tag>_kernel_stats.csv   per-kernel totals of the --stats pass (name, calls, total / average ns, share)
+   <tag>_traffic.json       per-kernel HBM bytes per launch from the PMC passes: 2 x FETCH_SIZE + WRITE_SIZE, in KiB -> bytes
+                            (gfx950: FETCH_SIZE reports half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM)"""
+import collections, csv, glob, json, os, shutil, sys
+
+out, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(out, sub, '**', f'*{suffix}'), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    for key in ('conv_halo_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel', 'conv_wgrad_rows_kernel', 'conv_wgrad_kernel',
+                'wgrad_reduce_kernel', 'upfirdn2d_fir_kernel', 'upfirdn2d_kernel', 'bias_act', 'scale_nc', 'dot_hw'):
+        if key in name:
+            return key
+    return name[:60]
+
+
+stats = find('stats', 'kernel_stats.csv')
+if stats:
+    shutil.copy(stats, os.path.join(here, f'{tag}_kernel_stats.csv'))
+per = collections.defaultdict(lambda: dict(launches=0, fetch_kib=0.0, write_kib=0.0))
+for sub, field in (('fetch', 'fetch_kib'), ('write', 'write_kib')):
+    f = find(sub, 'counter_collection.csv')
+    if not f:
+        continue
+    seen = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = short(r['Kernel_Name'])
+        per[k][field] += float(r['Counter_Value'])
+        seen[k] += 1
+    for k, n in seen.items():
+        per[k]['launches'] = max(per[k]['launches'], n)
+res = {}
+for k, v in per.items():
+    n = max(v['launches'], 1)
+    res[k] = dict(launches=v['launches'], fetch_bytes_per_launch=round(2 * v['fetch_kib'] * 1024 / n), write_bytes_per_launch=round(v['write_kib'] * 1024 / n),
+                  hbm_bytes_per_launch=round((2 * v['fetch_kib'] + v['write_kib']) * 1024 / n))
+json.dump(dict(command='python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline', formula='(2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch', kernels=res),
+          open(os.path.join(here, f'{tag}_traffic.json'), 'w'), indent=1, sort_keys=True)
+b = os.path.join(out, 'bench_under_rocprof.json')
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(here, f'{tag}_bench_under_rocprof.json'))
+print(json.dumps(res, indent=1)[:3000])
