@@ -57,6 +57,12 @@ if 'wgrad' in what:
         b = torch.randn(n, cb, r, r, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
         taps = [(i - 1, j - 1) for i in range(3) for j in range(3)]
         show(f"wgrad3x3 {ca}x{cb}@{r}", timed(lambda: cg._wgrad(a, b, 1, taps), reps=5))
+if 'wgrad2' in what:
+    for (n, ca, cb, r) in [(32, 256, 128, 128), (32, 512, 256, 64), (32, 512, 512, 32)]:     # stride 2: a on the coarse grid r x r, b on (2r+1)^2
+        a = torch.randn(n, ca, r, r, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(n, cb, 2 * r + 1, 2 * r + 1, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        taps = [(i, j) for i in range(3) for j in range(3)]
+        show(f"wgrad3x3 s2 {ca}x{cb}@{r}", timed(lambda: cg._wgrad(a, b, 2, taps), reps=5))
 if 'fir' in what:
     f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(dev)
     x = torch.randn(32, 128, 257, 257, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)

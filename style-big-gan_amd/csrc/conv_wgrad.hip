@@ -211,26 +211,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 #define SBG_OOB_OFFSET 0x80000000u
 
-template <class MF, int S>
+template <class MF, int S, int BCA>
 __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsigned a_bytes, unsigned b_bytes)
 {
-    // 8 waves = 2 (ca) x 4 (cb), wave tile 32 x 16 channels for all nine taps (72 accumulator registers): two waves per SIMD
-    // overlap one wave's barrier / transposing LDS reads with the other's MFMAs (the 4-wave version, 144 accumulators, ran at
-    // one wave per SIMD and spent 53 % of its wave cycles waiting).
+    // 8 waves = 2 (ca) x 4 (cb), wave tile (BCA / 2) x 16 channels for all nine taps: two waves per SIMD overlap one wave's
+    // barrier / transposing LDS reads with the other's MFMAs.  BCA = 128 (144 accumulator registers) halves the bytes staged per
+    // MFMA against BCA = 64 -- the L2 -> LDS stream, not the matrix pipe, bounds this kernel, most of all at stride 2 where the
+    // b patch of a 32-pixel chunk is 65 columns wide.
     // S = stride between the coarse (a) and fine (b) grids: b pixel = S * a pixel + tap, taps = (dy0 + i, dx0 + j), i, j in 0..2
-    constexpr int BC = 64, NT = 9, NSTAGE = 3, DEPTH = 2;
+    static_assert(BCA == 64 || BCA == 128, "a tile of 64 or 128 channels");
+    constexpr int BCB = 64, NT = 9, NSTAGE = 3, DEPTH = 2;
+    constexpr int TA = BCA / 32;                               // 16-channel a fragments per wave
+    constexpr int APIECES = BCA / 16;                          // a-tile = BCA / 64 sub-tiles of [32 pixels][64 channels], 4 pieces each
     constexpr int PCOLS = S * 31 + 3;                          // b columns needed by a 32-pixel chunk
     constexpr int PPR = (PCOLS + 7) / 8;                       // 8-pixel DMA pieces per patch row
     constexpr int PROW = PPR * 8;                              // patch row pitch in pixels
     constexpr int NWAVE = 8;
-    constexpr int NPIECE = ((4 + 3 * PPR + NWAVE - 1) / NWAVE) * NWAVE;   // a-tile (4) + patch pieces, padded with spares
+    constexpr int NPIECE = ((APIECES + 3 * PPR + NWAVE - 1) / NWAVE) * NWAVE;   // a-tile + patch pieces, padded with spares
     constexpr int PIECES = NPIECE / NWAVE;                     // DMA instructions per wave per stage
-    constexpr int A_BYTES = 32 * 128, STAGE = NPIECE * 1024;
+    constexpr int A_BYTES = APIECES * 1024, STAGE = NPIECE * 1024;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ca0 = blockIdx.x * BC, cb0 = blockIdx.y * BC, split = blockIdx.z;
+    const int ca0 = blockIdx.x * BCA, cb0 = blockIdx.y * BCB, split = blockIdx.z;
     const int chunk_begin = split * p.chunks_per_split;
     int chunk_end = chunk_begin + p.chunks_per_split;
     if (chunk_end > p.nchunks) chunk_end = p.nchunks;
@@ -254,14 +258,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
 #pragma unroll
         for (int i = 0; i < PIECES; i++) {
             const int piece = wave + NWAVE * i;                // wave-uniform
-            if (piece < 4) {                                   // a-tile rows 8*piece ..
-                const int R = piece * 8 + drow;
-                const int ch = ca0 + src_chunk(R) * 8;
+            if (piece < APIECES) {                             // a sub-tile piece >> 2, pixel rows 8 * (piece & 3) ..
+                const int R = (piece & 3) * 8 + drow;
+                const int ch = ca0 + (piece >> 2) * 64 + src_chunk(R) * 8;
                 const unsigned okm = 0u - (unsigned)(ch < p.Ca);
                 const unsigned real = (unsigned)(n * (int)p.as_n + py * (int)p.as_h + (px0 + R) * (int)p.as_w + ch) * 2u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_void_ptr)(st + piece * 1024), 16, (real & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
             } else {
-                const int q = piece - 4;                       // patch piece; q >= 3 * PPR are spares (zeros)
+                const int q = piece - APIECES;                 // patch piece; q >= 3 * PPR are spares (zeros)
                 const int r = q / PPR, jb = q - r * PPR;
                 const int R = r * PROW + jb * 8 + drow;        // LDS row inside the patch
                 const int by = S * py + dy0 + r, bx = S * px0 + dx0 + jb * 8 + drow;
@@ -273,13 +277,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         }
     };
 
-    const int wa = (wave >> 2) * 32, wb = (wave & 3) * 16;
+    const int wa = (wave >> 2) * (BCA / 2), wb = (wave & 3) * 16;
     const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
-    float4_t acc[NT][2][1];
+    float4_t acc[NT][TA];
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int i = 0; i < 2; i++) acc[t][i][0] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TA; i++) acc[t][i] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     // Per-lane LDS byte offsets of the transposing reads, computed once.  The tap order is fixed (t = 3 i + j), so inside the
     // chunk loop every read is `per-lane base (one of 3 column-tap variants) + compile-time constant`.
@@ -289,13 +293,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         const int sw = (((chunk >> 1) ^ ((Rrel >> 1) & 3)) << 1) | (chunk & 1);
         return Rrel * 128 + sw * 16 + (fp & 1) * 8;
     };
-    int offA[2], offB[3][1];
+    int offA[TA], offB[3];
 #pragma unroll
-    for (int i = 0; i < 2; i++) offA[i] = frag_off(4 * fg + fq, wa + 16 * i);
+    for (int i = 0; i < TA; i++) {
+        const int col = wa + 16 * i;                           // channel offset inside the a tile -> (sub-tile, column)
+        offA[i] = (col >> 6) * 4096 + frag_off(4 * fg + fq, col & 63);
+    }
 #pragma unroll
-    for (int d = 0; d < 3; d++)
-#pragma unroll
-        for (int j = 0; j < 1; j++) offB[d][j] = frag_off(d + S * (4 * fg + fq), wb + 16 * j);
+    for (int d = 0; d < 3; d++) offB[d] = frag_off(d + S * (4 * fg + fq), wb);
     auto read_frag = [&](const unsigned char* base, int off, int hi_off) -> short8_t {
         short4_t lo = lds_tr_read(base + off), hi = lds_tr_read(base + off + hi_off);
         return short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -310,39 +315,35 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         if (s + DEPTH < nloc) issue(s + DEPTH);
         const unsigned char* sA = smem + (s % NSTAGE) * STAGE;
         const unsigned char* sP = sA + A_BYTES;
-        short8_t fa[2];
+        short8_t fa[TA];
 #pragma unroll
-        for (int i = 0; i < 2; i++) fa[i] = read_frag(sA, offA[i], 16 * 128);
+        for (int i = 0; i < TA; i++) fa[i] = read_frag(sA, offA[i], 16 * 128);
 #pragma unroll
         for (int dyi = 0; dyi < 3; dyi++)
 #pragma unroll
             for (int dxi = 0; dxi < 3; dxi++) {
-                const short8_t fb = read_frag(sP + dyi * PROW * 128, offB[dxi][0], S * 16 * 128);
+                const short8_t fb = read_frag(sP + dyi * PROW * 128, offB[dxi], S * 16 * 128);
 #pragma unroll
-                for (int i = 0; i < 2; i++) acc[dyi * 3 + dxi][i][0] = Mfma<MF>::run(fa[i], fb, acc[dyi * 3 + dxi][i][0]);
+                for (int i = 0; i < TA; i++) acc[dyi * 3 + dxi][i] = Mfma<MF>::run(fa[i], fb, acc[dyi * 3 + dxi][i]);
             }
     }
 
     const bool direct = (p.nsplit == 1);
     float* dst_base = direct ? p.out : p.ws + (int64_t)split * p.ntaps_total * p.Ca * p.Cb;
+    const int cb = cb0 + wb + fi;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        if (t >= p.ntaps) continue;
+        if (t >= p.ntaps || cb >= p.Cb) continue;
         float* slab = dst_base + (int64_t)(p.tap0 + t) * p.Ca * p.Cb;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TA; i++)
 #pragma unroll
-            for (int j = 0; j < 1; j++) {
-                const int cb = cb0 + wb + 16 * j + fi;
-                if (cb >= p.Cb) continue;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int ca = ca0 + wa + 16 * i + 4 * fg + e;
-                    if (ca >= p.Ca) continue;
-                    float* d = slab + (int64_t)ca * p.Cb + cb;
-                    const float v = acc[t][i][j][e];
-                    *d = (direct && p.accumulate) ? *d + v : v;
-                }
+            for (int e = 0; e < 4; e++) {
+                const int ca = ca0 + wa + 16 * i + 4 * fg + e;
+                if (ca >= p.Ca) continue;
+                float* d = slab + (int64_t)ca * p.Cb + cb;
+                const float v = acc[t][i][e];
+                *d = (direct && p.accumulate) ? *d + v : v;
             }
     }
 }
@@ -376,6 +377,13 @@ static void plan_split_target(WgradArgs& a, int bca, int bcb, int target)
 
 static bool use_big_tile(int ntaps) { return ntaps == 1; }
 
+static int rows_bca(const WgradArgs& a)      // a-tile width of the rows kernel: 128 halves the staged bytes per MFMA
+{
+    static const char* e = getenv("SBG_WGRAD_BCA");
+    if (e) return atoi(e) == 64 ? 64 : 128;
+    return (a.stride == 2 && a.Ca >= 128) ? 128 : 64;     // measured: +46 % at stride 2 (65-column b patch), -7 % at stride 1
+}
+
 static bool rows_kernel_ok(const sbg_wgrad_params* q, const WgradArgs& a)
 {
     if (getenv("SBG_WGRAD_NO_DMA")) return false;
@@ -407,7 +415,7 @@ static int fill_args(const sbg_wgrad_params* q, WgradArgs& a)
     a.P = (int64_t)q->N * q->PH * q->PW;
     a.tap0 = 0; a.ntaps_total = q->ntaps;
     if (use_big_tile(q->ntaps)) plan_split(a, 128, 128); else plan_split(a, 64, 64);
-    if (rows_kernel_ok(q, a)) plan_split_target(a, 64, 64, 512);      // one resident workgroup per CU: two waves of workgroups, half the slab traffic
+    if (rows_kernel_ok(q, a)) plan_split_target(a, rows_bca(a), 64, 512);      // one resident workgroup per CU: two waves of workgroups, half the slab traffic
     return SBG_OK;
 }
 
@@ -456,24 +464,33 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
     if (rows_kernel_ok(q, a)) {
         const unsigned ab = (unsigned)(2 * ((int64_t)(q->N - 1) * q->as_n + (int64_t)(q->PH - 1) * q->as_h + (int64_t)(q->PW - 1) * q->as_w + q->Ca));
         const unsigned bb = (unsigned)(2 * ((int64_t)(q->N - 1) * q->bs_n + (int64_t)(q->BH - 1) * q->bs_h + (int64_t)(q->BW - 1) * q->bs_w + q->Cb));
-        const int lds = (q->stride == 1) ? 3 * 24 * 1024 : 3 * 32 * 1024;
+        const int bca = rows_bca(a);
+        const int s_ = q->stride;
+        // stage = (a pieces + 3 x patch pieces, rounded up to 8) KiB
+        auto stage_kib = [](int S, int BCA) { const int ppr = (S * 31 + 3 + 7) / 8; return ((BCA / 16 + 3 * ppr + 7) / 8) * 8; };
+        const int lds = 3 * stage_kib(s_, bca) * 1024;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(2, 64) * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(2, 64) * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(2, 128) * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(2, 128) * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(1, 128) * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(1, 128) * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(1, 64) * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(1, 64) * 1024);
             attr_set = true;
         }
         SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                           2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
-                          {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, 64064});
+                          {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, bca * 1000 + 64});
         const dim3 grid(a.atiles, a.btiles, a.nsplit);
-        if (q->stride == 1) {
-            if (bf) hipLaunchKernelGGL((conv_wgrad_rows_kernel<bf16_mfma, 1>), grid, dim3(512), lds, s, a, ab, bb);
-            else    hipLaunchKernelGGL((conv_wgrad_rows_kernel<f16_mfma, 1>), grid, dim3(512), lds, s, a, ab, bb);
-        } else {
-            if (bf) hipLaunchKernelGGL((conv_wgrad_rows_kernel<bf16_mfma, 2>), grid, dim3(512), lds, s, a, ab, bb);
-            else    hipLaunchKernelGGL((conv_wgrad_rows_kernel<f16_mfma, 2>), grid, dim3(512), lds, s, a, ab, bb);
-        }
+#define SBG_ROWS_LAUNCH(MFT, SS, BB) hipLaunchKernelGGL((conv_wgrad_rows_kernel<MFT, SS, BB>), grid, dim3(512), lds, s, a, ab, bb)
+        if (s_ == 1 && bca == 64)       { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 64);  else SBG_ROWS_LAUNCH(f16_mfma, 1, 64); }
+        else if (s_ == 1)               { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 128); else SBG_ROWS_LAUNCH(f16_mfma, 1, 128); }
+        else if (bca == 64)             { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 64);  else SBG_ROWS_LAUNCH(f16_mfma, 2, 64); }
+        else                            { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 128); else SBG_ROWS_LAUNCH(f16_mfma, 2, 128); }
+#undef SBG_ROWS_LAUNCH
         SBG_HIP_LAUNCH_CHECK();
     } else if (use_big_tile(a.ntaps)) {
         rc = bf ? launch_wgrad<bf16_mfma, 128, 128, 1>(a, s) : launch_wgrad<f16_mfma, 128, 128, 1>(a, s);
