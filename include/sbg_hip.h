@@ -158,6 +158,20 @@ int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layo
                int N, int C, int64_t HW, sbg_stream_t stream);
 
 
+/* Backward head of the fused modulated-convolution layer (train_parts/generators.py:79-88 + :328, i.e. modulated_conv2d's
+ * `fma(x, dcoefs, noise)` followed by bias_act): with y = clamp(act(c * dcoef[n,o] + noise[n,p] + bias[o]) * gain) saved,
+ * one pass over (dy, y) writes
+ *   d2[n,o,p]            = d1 * dcoef[n,o],  d1 = dy * gain * (y > 0 ? 1 : alpha) * [|y| < clamp]   (bias_act.py:159-210)
+ *   partial[0][s][n][o]  = sum_p d1                         (bias gradient)
+ *   partial[1][s][n][o]  = sum_p d1 * (pre - noise - bias)  (dcoef[n,o] * demodulation gradient; pre is recovered from y)
+ *   dnoise[n,p]          = sum_o d1                         (optional, NULL to skip)
+ * Channel-minor [N][HW][C] tensors, C / 8 a power of two <= 64; partial: fp32 [2][nsplit][N][C], nsplit = sbg_dot_hw_splits(1, N, C, HW).
+ * act in {linear, relu, lrelu}; clamp < 0 disables. */
+int sbg_modconv_bwd_supported(int C);
+int sbg_modconv_bwd(const void* dy, const void* y, const float* dcoef, const float* noise, const float* bias,
+                    void* d2, float* partial, float* dnoise, int dtype, int N, int C, int64_t HW, int64_t noise_stride_n,
+                    int act, float alpha, float gain, float clamp, sbg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Spectral norm, one power iteration with one singular vector (biggan/layers.py `power_iteration` :28-50, `SN.W_` :87-99):
  *   v = normalize(u W), u' = normalize(v W^T), sigma = (v W^T) . u'        W: fp32 [rows, cols] row-major, u: fp32 [rows]

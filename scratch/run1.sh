@@ -1,2 +1,2 @@
-python -m pytest tests -m gpu -x -q -k "conv" 2>&1 | tail -2
-for v in 64 128; do echo "== BCA=$v"; SBG_WGRAD_BCA=$v timeout -k 10 120 python scratch/kbench.py wgrad wgrad2 2>&1 | grep "conv_wgrad"; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout -k 10 400 python bench.py --no-cpu-baseline --kernel-breakdown > gpurun_out/s14_bench.json 2> gpurun_out/s14_bench_breakdown.log; cat gpurun_out/s14_bench.json | cut -c1-1700

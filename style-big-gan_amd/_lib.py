@@ -97,6 +97,8 @@ SYMBOLS = [
     ("sbg_attention_fwd", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_dot_hw_splits", _c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64]),
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
+    ("sbg_modconv_bwd_supported", _c.c_int, [_c.c_int]),
+    ("sbg_modconv_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
     ("sbg_prof_enable", _c.c_int, [_c.c_int]),
     ("sbg_prof_fetch", _c.c_int, [_c.POINTER(ProfRecord), _c.c_int]),
 ]

@@ -152,6 +152,91 @@ __global__ __launch_bounds__(256) void dot_hw_generic(DotArgs p, int layout)
     if (threadIdx.x == 0) p.partial[nc] = red[0];
 }
 
+// ---- modconv_bwd -----------------------------------------------------------------------------------------------------
+// Backward head of the fused modulated-convolution layer  y = clamp(lrelu(c * dcoef[n,o] + noise[n,p] + b[o]) * gain):
+// ONE pass over (dy, y) yields everything that does not need a convolution,
+//     d1 = dy * gain * (y > 0 ? 1 : alpha) * [|y| < clamp]                (= dL/dpre, bias_act.py:159-210 on the saved output)
+//     d2[n,o,p]        = d1 * dcoef[n,o]                                  (dL/dc, the input of the data / weight gradient convs)
+//     part[0][s][n][o] = sum_{p in split s} d1                            (bias gradient, summed over n and s by the caller)
+//     part[1][s][n][o] = sum_{p in split s} d1 * (pre - noise - b)        (= dcoef * sum d1 * c: demodulation gradient)
+//     dnoise[n,p]      = sum_o d1                                         (optional)
+// with pre recovered from the saved output (the activation is piecewise linear and invertible; clamped elements carry no
+// gradient), so the pre-activation tensor c is never written or read.  Same workgroup shape and fixed-order reduction as
+// dot_hw_cminor8: channel-minor, C / 8 a power of two <= 64.
+struct ModBwdArgs {
+    const void* dy; const void* y; const float* dcoef; const float* noise; const float* bias;
+    void* d2; float* part; float* dnoise;
+    int N, C; int64_t HW, nsn; int nsplit; int64_t pix_per_split;
+    float alpha, gain, clamp;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void modconv_bwd_kernel(ModBwdArgs p)
+{
+    __shared__ float red[256 * 16];
+    const T* pdy = (const T*)p.dy; const T* py = (const T*)p.y; T* pd2 = (T*)p.d2;
+    const int n = blockIdx.x, s = blockIdx.y;
+    const int cv = p.C >> 3;
+    const int64_t p0 = (int64_t)s * p.pix_per_split;
+    int64_t p1 = p0 + p.pix_per_split; if (p1 > p.HW) p1 = p.HW;
+    const int64_t base = (int64_t)n * p.HW * p.C;
+    const int myc = threadIdx.x % cv, plane = threadIdx.x / cv, planes = 256 / cv;
+    float dc[8], bb[8], s1[8], s2[8];
+    Vec8<float>::ld(p.dcoef + (int64_t)n * p.C + (myc << 3), dc);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { bb[j] = p.bias ? p.bias[(myc << 3) + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    const float inv_pos = 1.f / p.gain, inv_neg = p.alpha > 0.f ? 1.f / (p.gain * p.alpha) : 0.f;
+    const float gpos = p.gain, gneg = p.gain * p.alpha;
+    const float cl = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+    // every lane of a wave runs the same number of iterations (pixel lanes of one wave differ by < planes), so the
+    // cross-lane channel sum below sees all lanes of a pixel
+    const int64_t iters = (p1 - p0 + planes - 1) / planes;
+    for (int64_t it = 0; it < iters; it++) {
+        const int64_t pix = p0 + it * planes + plane;
+        const bool ok = pix < p1;
+        float g[8], yv[8], o[8];
+        float dn = 0.f;
+        if (ok) {
+            const int64_t off = base + pix * p.C + (myc << 3);
+            Vec8<T>::ld(pdy + off, g);
+            Vec8<T>::ld(py + off, yv);
+            const float nz = p.noise ? p.noise[n * p.nsn + pix] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const bool pos = yv[j] > 0.f;
+                const bool live = (yv[j] > -cl) && (yv[j] < cl);
+                const float d1 = live ? g[j] * (pos ? gpos : gneg) : 0.f;
+                const float pre = yv[j] * (pos ? inv_pos : inv_neg);
+                s1[j] += d1;
+                s2[j] += d1 * (pre - nz - bb[j]);
+                dn += d1;
+                o[j] = d1 * dc[j];
+            }
+            Vec8<T>::st(pd2 + off, o);
+        }
+        if (p.dnoise) {                                 // sum over the cv lanes that hold this pixel's channels (cv <= 64, power of two)
+            for (int m = 1; m < cv; m <<= 1) dn += __shfl_xor(dn, m, 64);
+            if (ok && myc == 0) p.dnoise[(int64_t)n * p.HW + pix] = dn;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
+    __syncthreads();
+    for (int stride = planes >> 1; stride >= 1; stride >>= 1) {      // fixed-order tree over the pixel lanes
+        if (plane < stride) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) red[threadIdx.x * 16 + j] += red[(threadIdx.x + stride * cv) * 16 + j];
+        }
+        __syncthreads();
+    }
+    if (plane == 0) {
+        float* d0 = p.part + ((int64_t)s * p.N + n) * p.C + (myc << 3);
+        float* d1p = d0 + (int64_t)p.nsplit * p.N * p.C;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { d0[j] = red[threadIdx.x * 16 + j]; d1p[j] = red[threadIdx.x * 16 + 8 + j]; }
+    }
+}
+
 static bool dot_fast(int layout, int C) { return layout == 1 && (C % 8) == 0; }
 
 template <class T>
@@ -245,4 +330,37 @@ extern "C" int sbg_dot_hw(const void* u, const void* v, float* partial, int dtyp
     if (dtype == SBG_F32) return run_dot<float>(p, layout, fast, s);
     if (dtype == SBG_F16) return run_dot<f16_s>(p, layout, fast, s);
     return run_dot<bf16_s>(p, layout, fast, s);
+}
+
+
+extern "C" int sbg_modconv_bwd_supported(int C)
+{
+    const int cv = C >> 3;
+    return (C % 8) == 0 && cv >= 1 && cv <= 64 && (cv & (cv - 1)) == 0;
+}
+
+extern "C" int sbg_modconv_bwd(const void* dy, const void* y, const float* dcoef, const float* noise, const float* bias,
+                               void* d2, float* partial, float* dnoise, int dtype, int N, int C, int64_t HW, int64_t noise_stride_n,
+                               int act, float alpha, float gain, float clamp, sbg_stream_t stream)
+{
+    SBG_CHECK(dy && y && dcoef && d2 && partial, "modconv_bwd: null pointer");
+    SBG_CHECK(dtype == SBG_F16 || dtype == SBG_BF16 || dtype == SBG_F32, "modconv_bwd: unsupported dtype %d", dtype);
+    SBG_CHECK(sbg_modconv_bwd_supported(C), "modconv_bwd: C / 8 must be a power of two <= 64 (got C = %d)", C);
+    SBG_CHECK(act == SBG_ACT_LINEAR || act == SBG_ACT_RELU || act == SBG_ACT_LRELU, "modconv_bwd: activation must be linear, relu or lrelu");
+    SBG_CHECK(N >= 1 && HW >= 1 && gain > 0.f, "modconv_bwd: bad sizes / gain");
+    SBG_CHECK(sbg_aligned16(dy) && sbg_aligned16(y) && sbg_aligned16(d2) && sbg_aligned16(dcoef), "modconv_bwd: tensors must be 16-byte aligned");
+    ModBwdArgs p;
+    p.dy = dy; p.y = y; p.dcoef = dcoef; p.noise = noise; p.bias = bias; p.d2 = d2; p.part = partial; p.dnoise = dnoise;
+    p.N = N; p.C = C; p.HW = HW; p.nsn = noise_stride_n;
+    p.nsplit = sbg_dot_hw_splits(1, N, C, HW);
+    p.pix_per_split = (HW + p.nsplit - 1) / p.nsplit;
+    p.alpha = act == SBG_ACT_LRELU ? alpha : (act == SBG_ACT_RELU ? 0.f : 1.f); p.gain = gain; p.clamp = clamp;
+    hipStream_t s = (hipStream_t)stream;
+    const double es = dtype == SBG_F32 ? 4 : 2;
+    SbgProfScope prof(s, SBG_K_DOT_HW, 0.0, 3.0 * es * N * (double)C * HW, {N, C, (int)HW, 2});
+    if (dtype == SBG_F32)      hipLaunchKernelGGL((modconv_bwd_kernel<float>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    else if (dtype == SBG_F16) hipLaunchKernelGGL((modconv_bwd_kernel<f16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    else                       hipLaunchKernelGGL((modconv_bwd_kernel<bf16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
 }

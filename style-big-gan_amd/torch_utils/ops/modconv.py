@@ -1,0 +1,96 @@
+"""Training-time modulated convolution with its whole tail in the convolution kernel's epilogue.
+
+The reference's synthesis layer runs ``modulated_conv2d`` (``x * styles`` -> convolution -> ``fma(x, dcoefs, noise)``,
+train_parts/generators.py:79-88) and then ``bias_act`` (:328): three full passes over the activation besides the convolution.
+Here the forward is ``scale_nc`` + ONE convolution launch whose epilogue applies demodulation, noise, bias, activation, gain and
+clamp (csrc/conv_k64.hip), and the backward starts with ONE pass over ``(dy, y)`` (``sbg_modconv_bwd``, csrc/modulate.hip) that
+produces the gradient fed to the data / weight gradient convolutions together with the bias, demodulation and noise gradients;
+the pre-activation tensor is never materialised (the activation is piecewise linear, so it is recovered from the saved output).
+
+First order only: path-length regularisation differentiates twice through the synthesis network, so trainers switch ``enabled``
+off when a generator regulariser is configured and the layer falls back to the differentiable composition.
+"""
+import torch
+
+from ... import _lib
+from . import bias_act as _ba
+from . import conv2d_gradfix as _cg
+from . import modulate as _mod
+
+enabled = True      # module switch: False -> SynthesisLayer uses modulated_conv2d + bias_act (arbitrarily differentiable)
+
+_ACT = {"linear": 1, "relu": 2, "lrelu": 3}
+
+
+def usable(x, weight, act, up):
+    return (enabled and up == 1 and act in _ACT and x.device.type == "cuda" and x.dtype in (torch.bfloat16, torch.float16)
+            and weight.shape[2] == weight.shape[3] and bool(_lib.load().sbg_modconv_bwd_supported(weight.shape[0])))
+
+
+class _ModConvBiasAct(torch.autograd.Function):
+    """y = clamp(act(conv(x * s, w) * dcoefs + noise + b) * gain);  cfg = (padding, act, alpha, gain, clamp)"""
+
+    @staticmethod
+    def forward(ctx, x, w, styles, dcoefs, noise, b, cfg):
+        padding, act, alpha, gain, clamp = cfg
+        xs = _mod._scale_nc_launch(x, styles, None)
+        epi = _cg.Epilogue(oscale=dcoefs, noise=noise, bias=b, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        y = _cg._conv_forward(xs, w, (1, 1), (padding, padding), epi=epi)
+        ctx.save_for_backward(x, xs, w, styles, dcoefs, noise, b, y)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xs, w, styles, dcoefs, noise, b, y = ctx.saved_tensors
+        padding, act, alpha, gain, clamp = ctx.cfg
+        if torch.is_grad_enabled():
+            raise RuntimeError("modconv: the fused layer is first-order only; set torch_utils.ops.modconv.enabled = False "
+                               "before building a graph that is differentiated twice (path-length regularisation)")
+        lib = _lib.load()
+        n, cout, h, wd = y.shape
+        dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
+        dc32 = dcoefs.detach().to(torch.float32).reshape(n, cout).contiguous()
+        nz = nsn = None
+        if noise is not None:
+            nz = noise.detach().to(torch.float32)
+            per_sample = nz.numel() != h * wd
+            nz = nz.reshape(n if per_sample else 1, h * wd).contiguous()
+            nsn = h * wd if per_sample else 0
+        b32 = b.detach().to(torch.float32).contiguous() if b is not None else None
+        ns = lib.sbg_dot_hw_splits(1, n, cout, h * wd)
+        part = torch.empty([2, ns, n, cout], dtype=torch.float32, device=y.device)
+        d2 = torch.empty_like(y)
+        want_dn = noise is not None and ctx.needs_input_grad[4]
+        dn = torch.empty([n, 1, h, wd], dtype=torch.float32, device=y.device) if want_dn else None
+        _lib.check(lib.sbg_modconv_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dc32), _lib.ptr(nz), _lib.ptr(b32), _lib.ptr(d2), _lib.ptr(part),
+                                       _lib.ptr(dn), _lib.dtype_code(y.dtype), n, cout, h * wd, nsn or 0, _ACT[act], float(alpha), float(gain),
+                                       float(clamp), _lib.stream_ptr(y.device)), "sbg_modconv_bwd")
+        sums = part.sum(1)                                   # [2, N, Cout], fixed order
+        dx = dw = dstyles = ddcoefs = dnoise = db = None
+        if ctx.needs_input_grad[3]:
+            ddcoefs = (sums[1] / dc32).to(dcoefs.dtype).reshape(dcoefs.shape)
+        if b is not None and ctx.needs_input_grad[5]:
+            db = sums[0].sum(0).to(b.dtype)
+        if want_dn:
+            dnoise = dn if noise.numel() != h * wd else dn.sum(0, keepdim=True)
+            dnoise = dnoise.reshape(noise.shape).to(noise.dtype)
+        ccfg = (False, (1, 1), (padding, padding), (0, 0))
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            dxs = _cg._Conv.apply(d2, w, (True, (1, 1), (padding, padding), (0, 0)))
+            if ctx.needs_input_grad[0]:
+                dx = _mod._scale_nc_launch(dxs, styles, None)
+            if ctx.needs_input_grad[2]:
+                dstyles = _mod._dot_hw_launch(dxs, x).to(styles.dtype).reshape(styles.shape)
+        if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
+            dw = _cg._ConvWgrad.apply(d2, xs, ccfg, tuple(w.shape))
+        return dx, dw, dstyles, ddcoefs, dnoise, db, None
+
+
+def modconv_bias_act(x, weight, styles, dcoefs, noise, bias, padding, act="lrelu", alpha=None, gain=None, clamp=None):
+    """Fused SynthesisLayer body (up = 1): x [N, Cin, H, W] 16-bit, weight [Cout, Cin, k, k] same dtype, styles [N, Cin],
+    dcoefs [N, Cout] (demodulation coefficients, differentiable), noise None / [N, 1, H, W] / [H, W], bias [Cout]."""
+    spec = _ba.activation_funcs[act]
+    cfg = (int(padding), act, float(alpha if alpha is not None else spec.def_alpha), float(gain if gain is not None else spec.def_gain),
+           float(clamp if clamp is not None else -1))
+    return _ModConvBiasAct.apply(x, weight, styles, dcoefs, noise, bias, cfg)

@@ -22,7 +22,7 @@ import torch
 
 from .. import utils
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, conv_bias_act, modulate, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, conv_bias_act, modconv, modulate, upfirdn2d
 
 generators = utils.ClassRegistry()
 
@@ -271,6 +271,10 @@ class SynthesisLayer(torch.nn.Module):
                 epi = conv2d_gradfix.Epilogue(oscale=dcoefs, noise=noise, bias=self.bias, act=self.activation, alpha=spec.def_alpha,
                                               gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1))
                 return conv2d_gradfix._conv_forward(xs, self.weight.to(x.dtype), (1, 1), (self.padding, self.padding), epi=epi)
+        if modconv.usable(x, self.weight, self.activation, self.up):
+            # training pass, first order: same fused epilogue, plus a one-pass backward head (torch_utils/ops/modconv.py)
+            return modconv.modconv_bias_act(x, self.weight.to(x.dtype), styles, demod_coefficients(self.weight, styles), noise, self.bias,
+                                            padding=self.padding, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)

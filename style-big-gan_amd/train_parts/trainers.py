@@ -78,6 +78,9 @@ class StepEngine:
             self.dp_modules = dict(G=GradReducer(self.G, **dp), D=GradReducer(self.D, **dp))
             la = dict(G=self.dp_modules['G'])
         la.update(loss_arch_kwargs or {})
+        # the fused training-time synthesis layer is first order only: generator regularisers (path length) differentiate twice
+        from ..torch_utils.ops import modconv
+        modconv.enabled = len(list(gen_regs)) == 0
         self.loss = losses_arch[loss_arch](device=self.device, gen_regs=list(gen_regs), dis_regs=list(dis_regs),
                                            D=self.dp_modules['D'], loss=loss, **la)
 

@@ -299,3 +299,49 @@ def test_fused_conv_bias_act_epilogue(dev):
     ref = O.bias_act(torch.nn.functional.conv2d(xq, wq, padding=1), bq, act="lrelu", clamp=1.0)
     got = conv_bias_act.conv2d_bias_act(xq.to(dev, torch.bfloat16), wq.to(dev, torch.bfloat16), bq.to(dev, torch.bfloat16), padding=1, act="lrelu", clamp=1.0)
     check(got, ref, 2e-2, "fused conv+bias_act vs oracle")
+
+
+def test_fused_modconv_training_layer(dev):
+    """SynthesisLayer body: fused epilogue + one-pass backward head (ops/modconv.py) vs the modulated_conv2d + bias_act composition.
+    Both run in bf16 and individual activation / clamp masks flip between any two bf16 evaluation orders, so each path is held to
+    an fp64 restatement of the reference layer (generators.py:79-88,328) on the same inputs and the same dy: the fused path must be
+    at least as close as the composition (x1.5 + 5e-3 slack) for y and every first-order gradient."""
+    from style_big_gan_amd.torch_utils.ops import modconv
+    from style_big_gan_amd.train_parts import generators as GN
+    F = torch.nn.functional
+    torch.manual_seed(11)
+
+    def ref_layer(x, w, s, nz, b, act, gain, clamp):
+        dco = ((w[None] * s[:, None, :, None, None]).square().sum([2, 3, 4]) + 1e-8).rsqrt()
+        pre = F.conv2d(x * s[:, :, None, None], w, padding=1) * dco[:, :, None, None] + (nz if nz is not None else 0) + b[None, :, None, None]
+        y = (F.leaky_relu(pre, 0.2) if act == "lrelu" else pre) * gain
+        return y.clamp(-clamp, clamp) if clamp is not None else y
+
+    def err(a, b):
+        return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
+
+    for (n, cin, cout, r, act, clamp, noise_kind) in [(2, 16, 128, 16, "lrelu", 2.0, "per_sample"), (3, 24, 64, 8, "lrelu", None, "const"),
+                                                      (2, 8, 128, 16, "linear", 1.0, None), (4, 64, 128, 32, "lrelu", None, "per_sample")]:
+        x0 = torch.randn(n, cin, r, r, device=dev).to(torch.bfloat16)
+        w0 = torch.randn(cout, cin, 3, 3, device=dev).to(torch.bfloat16).float()
+        s0 = torch.randn(n, cin, device=dev) + 1
+        b0 = torch.randn(cout, device=dev)
+        nz0 = None if noise_kind is None else torch.randn((n, 1, r, r) if noise_kind == "per_sample" else (r, r), device=dev)
+        dy0 = torch.randn(n, cout, r, r, device=dev).to(torch.bfloat16)
+        res = {}
+        for mode in ("fused", "unfused", "ref"):
+            cast = (lambda t: t.double()) if mode == "ref" else (lambda t: t.clone())
+            x, w, s, b = [cast(t).requires_grad_(True) for t in (x0, w0, s0, b0)]
+            nz = None if nz0 is None else cast(nz0).requires_grad_(True)
+            if mode == "fused":
+                assert modconv.usable(x, w, act, 1)
+                y = modconv.modconv_bias_act(x, w.to(x.dtype), s, GN.demod_coefficients(w, s), nz, b, padding=1, act=act, gain=1.3, clamp=clamp)
+            elif mode == "unfused":
+                y = bias_act.bias_act(GN.modulated_conv2d(x=x, weight=w, styles=s, noise=nz, padding=1), b.to(torch.bfloat16), act=act, gain=1.3, clamp=clamp)
+            else:
+                y = ref_layer(x, w, s, nz, b, act, 1.3, clamp)
+            g = torch.autograd.grad((y.double() * dy0.double()).sum(), [x, w, s, b] + ([nz] if nz is not None else []))
+            res[mode] = [y.detach()] + [t.detach() for t in g]
+        for name, f_, u_, r_ in zip(["y", "dx", "dw", "dstyles", "db", "dnoise"], res["fused"], res["unfused"], res["ref"]):
+            ef, eu = err(f_, r_), err(u_, r_)
+            assert ef <= 1.5 * eu + 5e-3, f"modconv {name} ({act}, {noise_kind}, clamp {clamp}): fused {ef:.3e} vs composition {eu:.3e}"
