@@ -108,8 +108,14 @@ typedef struct sbg_conv_params {
     int accumulate;
     const float* bias; const float* noise; int64_t noise_stride_n;
     int act; float alpha, gain, clamp;
+    /* Optional split of the reduction (taps x channels) over `ksplit` workgroups per output tile, for launches with too few
+     * output tiles to fill the chip (the 4x4 / 8x8 blocks): partial fp32 results go to `workspace`
+     * (>= sbg_conv2d_igemm_workspace() bytes) and a second kernel sums them in a fixed order into y (bitwise reproducible).
+     * Needs a dense fp32 y without fused epilogue; ksplit <= 1 or workspace == NULL = off. */
+    void* workspace; int ksplit;
 } sbg_conv_params;
-int sbg_conv2d_igemm(const sbg_conv_params* p, sbg_stream_t stream);
+int64_t sbg_conv2d_igemm_workspace(const sbg_conv_params* p);
+int     sbg_conv2d_igemm(const sbg_conv_params* p, sbg_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -51,6 +51,7 @@ class ConvParams(ctypes.Structure):
         ("accumulate", ctypes.c_int),
         ("bias", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("noise_stride_n", ctypes.c_int64),
         ("act", ctypes.c_int), ("alpha", ctypes.c_float), ("gain", ctypes.c_float), ("clamp", ctypes.c_float),
+        ("workspace", ctypes.c_void_p), ("ksplit", ctypes.c_int),
     ]
 
 
@@ -86,6 +87,7 @@ SYMBOLS = [
     ("sbg_bias_act", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
                                                    _c.c_int64, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
+    ("sbg_conv2d_igemm_workspace", _c.c_int64, [_c.POINTER(ConvParams)]),
     ("sbg_conv2d_igemm", _c.c_int, [_c.POINTER(ConvParams), _c.c_void_p]),
     ("sbg_conv2d_wgrad_workspace", _c.c_int64, [_c.POINTER(WgradParams)]),
     ("sbg_conv2d_wgrad", _c.c_int, [_c.POINTER(WgradParams), _c.c_void_p]),

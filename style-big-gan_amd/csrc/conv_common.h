@@ -32,6 +32,8 @@ struct ConvArgs {
     int accumulate;
     int P;            // N * OH * OW output pixels of this launch
     int ptiles, ctiles;
+    int ksplit;               // gather kernel: the K-steps are split over gridDim.y workgroups, each writing its own fp32 slab
+    int64_t y_split_stride;   // elements between the slabs (0 when ksplit == 1)
     int debug;        // ablation switches, honoured only by -DSBG_K64_DEBUG builds (diagnosis; see conv_k64.hip)
 };
 
@@ -39,4 +41,4 @@ struct ConvArgs {
 
 // conv_k64.hip: K-step-64 LDS-DMA kernels (gather and halo-staged).  Returns SBG_OK / an error, or -1 when the launch does not
 // fit these kernels (the caller then uses the kernels of conv_igemm.hip).
-int sbg_conv_k64_dispatch(sbgconv::ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, hipStream_t stream);
+int sbg_conv_k64_dispatch(sbgconv::ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, void* workspace, int ksplit, hipStream_t stream);

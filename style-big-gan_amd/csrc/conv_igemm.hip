@@ -412,6 +412,7 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     SBG_CHECK(q->ntaps >= 1 && q->ntaps <= SBG_MAX_TAPS, "conv2d_igemm: 1..%d taps", SBG_MAX_TAPS);
     SBG_CHECK(q->stride >= 1, "conv2d_igemm: stride must be >= 1");
     SBG_CHECK(!q->accumulate || q->ydtype == SBG_F32, "conv2d_igemm: accumulate needs an fp32 output");
+    SBG_CHECK(q->ksplit <= 1 || (q->workspace != nullptr && q->ydtype == SBG_F32), "conv2d_igemm: ksplit > 1 needs a workspace and an fp32 output");
     SBG_CHECK(q->act == 0 || q->act == SBG_ACT_LINEAR || q->act == SBG_ACT_RELU || q->act == SBG_ACT_LRELU, "conv2d_igemm: fused activation must be linear, relu or lrelu");
     SBG_CHECK(sbg_aligned16(q->x) && sbg_aligned16(q->w), "conv2d_igemm: x and w must be 16-byte aligned");
     SBG_CHECK((q->xs_n % 8) == 0 && (q->xs_h % 8) == 0 && (q->xs_w % 8) == 0 && (q->ws_slab % 8) == 0 && (q->ws_co % 8) == 0,
@@ -431,7 +432,7 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     a.stride = q->stride; a.ntaps = q->ntaps;
     for (int t = 0; t < SBG_MAX_TAPS; t++) { a.tap_dy[t] = q->tap_dy[t]; a.tap_dx[t] = q->tap_dx[t]; a.tap_slab[t] = q->tap_slab[t]; }
     a.accumulate = q->accumulate;
-    a.P = (int)P; a.ptiles = a.ctiles = 0; a.debug = 0;
+    a.P = (int)P; a.ptiles = a.ctiles = 0; a.debug = 0; a.ksplit = 1; a.y_split_stride = 0;
     hipStream_t s = (hipStream_t)stream;
     int maxslab = 0;
     for (int t = 0; t < q->ntaps; t++) { SBG_CHECK(q->tap_slab[t] >= 0, "conv2d_igemm: negative weight slab"); if (q->tap_slab[t] > maxslab) maxslab = q->tap_slab[t]; }
@@ -439,7 +440,7 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     const int64_t w_bytes = 2 * ((int64_t)maxslab * q->ws_slab + (int64_t)(q->Cout - 1) * q->ws_co + q->Cin);
     const bool allow_dma = getenv("SBG_CONV_NO_DMA") == nullptr && q->xs_n >= 0 && q->xs_h >= 0 && q->xs_w >= 0 && q->ws_slab >= 0 && q->ws_co >= 0;
     if (allow_dma) {      // K-step-64 kernels (conv_k64.hip) take every launch whose operands fit a 2 GiB buffer descriptor
-        const int rc = sbg_conv_k64_dispatch(a, q->xdtype == SBG_BF16, x_bytes, w_bytes, s);
+        const int rc = sbg_conv_k64_dispatch(a, q->xdtype == SBG_BF16, x_bytes, w_bytes, q->workspace, q->ksplit, s);
         if (rc >= 0) return rc;
     }
     if (q->xdtype == SBG_BF16) return dispatch_conv<bf16_mfma>(a, x_bytes, w_bytes, allow_dma, s);

@@ -73,7 +73,7 @@ static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, flo
     for (int j = 0; j < TP; j++) {
         int n, oy, ox;
         if (!pix(j, n, oy, ox)) continue;
-        const int64_t yoff = (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
+        const int64_t yoff = (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
         float nz = 0.f;
         if (!PLAIN && p.noise) nz = p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox];
         const float* sc = p.oscale + (int64_t)n * p.Cout + cbase + 8 * fg;
@@ -139,7 +139,7 @@ static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_
     for (int j = 0; j < TP; j++) {
         int n, oy, ox;
         if (!pix(j, n, oy, ox)) continue;
-        const int64_t yoff = (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
+        const int64_t yoff = (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
         const float nz = (!plain && p.noise) ? p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox] : 0.f;
 #pragma unroll
         for (int h = 0; h < TH2; h++) {
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
         a_base[i] = (co < p.Cout) ? (unsigned)(co * (int)p.ws_co + src_k) * 2u : SBG_OOB_OFFSET;
     }
     const int kchunks = (p.Cin + 63) >> 6;
-    const int nsteps = p.ntaps * kchunks;
+    const int nsteps_all = p.ntaps * kchunks;
+    int nsteps = nsteps_all;
     // per-tap constants live in lane t of a VGPR and are fetched with v_readlane (no scalar-memory latency inside the K loop)
     const int tl = lane < p.ntaps ? lane : 0;
     const int tbl_dy = p.tap_dy[tl], tbl_dx = p.tap_dx[tl];
@@ -309,13 +310,21 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
         constexpr int C = IA + IB;                       // DMA instructions per wave per step
         static_assert(LEAD == 2, "gather pipeline: two steps of loads in flight");
         // steps are tap-major: step = t * kchunks + chunk; (it, ic) = coordinates of the step whose loads are issued next
-        int it = 0, ic = 0, wstage = 0;
+        // split K: workgroup blockIdx.y of gridDim.y takes steps [s_begin, s_begin + nsteps)
+        int s_begin = 0;
+        if (p.ksplit > 1) {
+            const int per = (nsteps_all + p.ksplit - 1) / p.ksplit;
+            s_begin = blockIdx.y * per;
+            nsteps = nsteps_all - s_begin < per ? nsteps_all - s_begin : per;
+            if (nsteps < 0) nsteps = 0;
+        }
+        int it = s_begin / kchunks, ic = s_begin - it * kchunks, wstage = 0;
         auto issue_next = [&]() {
             issue_w(it, ic, wstage); issue_x(it, ic, wstage);
             wstage = wstage == NSTAGE - 1 ? 0 : wstage + 1;
             if (++ic == kchunks) { ic = 0; it++; }
         };
-        issue_next();
+        if (nsteps > 0) issue_next();
         if (nsteps > 1) { issue_next(); wait_vmcnt_const<C>(); } else wait_vmcnt_const<0>();
         if (grpY) __builtin_amdgcn_s_barrier();
         int stage = 0;
@@ -615,9 +624,22 @@ static int launch_k64(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
                       {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 1000000 + BC * 1000 + BP});
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, stream, a, x_bytes, w_bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)(a.ksplit > 1 ? a.ksplit : 1)), dim3(512), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
+}
+
+// y[i] (+)= sum_k ws[k][i] in a fixed order; 16 lanes share an output element (slabs k, k + 16, ...), then a shuffle tree.
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* ws, float* y, int64_t n, int ksplit, int accumulate)
+{
+    const int sub = threadIdx.x & 15;
+    const int64_t step = (int64_t)gridDim.x * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < n; i += step) {
+        float s = 0.f;
+        for (int k = sub; k < ksplit; k += 16) s += ws[(int64_t)k * n + i];
+        for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (sub == 0) y[i] = accumulate ? y[i] + s : s;
+    }
 }
 
 template <class MF>
@@ -632,13 +654,30 @@ static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStr
         if (a.OW % 16 == 0 && a.OH % 16 == 0) return launch_halo_ld<MF, 16, 16>(a, xb, wb, stream);
     }
     if (a.Cout <= 64) return launch_k64<MF, 64, 256, 1, 8>(a, xb, wb, stream);
+    if (a.ksplit > 1) return launch_k64<MF, 128, 128, 2, 4>(a, xb, wb, stream);        // the caller wraps this launch with the slab reduction
     if (tiles256 < 256) return launch_k64<MF, 128, 128, 2, 4>(a, xb, wb, stream);
     return launch_k64<MF, 128, 256, 2, 4>(a, xb, wb, stream);
 }
 
 } // namespace
 
-int sbg_conv_k64_dispatch(ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, hipStream_t stream)
+// Split-K is worth it when the output tiles alone leave most CUs idle and the reduction is long: returns the split actually used.
+static int plan_ksplit(const ConvArgs& a, int ksplit)
+{
+    if (ksplit <= 1 || a.Cout <= 64) return 1;
+    const int nsteps = a.ntaps * ((a.Cin + 63) >> 6);
+    int k = ksplit;
+    if (k > nsteps / 4) k = nsteps / 4;             // at least four K-steps per workgroup
+    return k < 2 ? 1 : k;
+}
+
+extern "C" int64_t sbg_conv2d_igemm_workspace(const sbg_conv_params* q)
+{
+    if (!q || q->ksplit <= 1) return 0;
+    return (int64_t)q->ksplit * q->N * q->OH * q->OW * q->Cout * (int64_t)sizeof(float);
+}
+
+int sbg_conv_k64_dispatch(ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, void* workspace, int ksplit, hipStream_t stream)
 {
     if (x_bytes >= (int64_t)SBG_OOB_OFFSET || w_bytes >= (int64_t)SBG_OOB_OFFSET) return -1;
     if (a.xs_n < 0 || a.xs_h < 0 || a.xs_w < 0 || a.ws_slab < 0 || a.ws_co < 0) return -1;
@@ -650,6 +689,21 @@ int sbg_conv_k64_dispatch(ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_byt
     { const char* e3 = getenv("SBG_K64_ABL"); a.debug = e3 ? atoi(e3) : 0; }
 #endif
     const unsigned xb = (unsigned)x_bytes, wb = (unsigned)w_bytes;
+    const int64_t y_numel = (int64_t)a.P * a.Cout;
+    const bool dense_y = a.ys_w == a.Cout && a.ys_h == (int64_t)a.OW * a.Cout && a.ys_n == (int64_t)a.OH * a.OW * a.Cout;
+    const bool plain = (a.act <= SBG_ACT_LINEAR) && a.gain == 1.f && a.clamp < 0.f && !a.bias && !a.noise && !a.oscale;
+    const int k = (workspace && a.ydtype == SBG_F32 && dense_y && plain) ? plan_ksplit(a, ksplit) : 1;
+    if (k > 1) {
+        ConvArgs b = a;
+        void* y = a.y; const int acc = a.accumulate;
+        b.y = workspace; b.accumulate = 0; b.ksplit = k; b.y_split_stride = y_numel;
+        const int rc = bf16 ? dispatch_k64<bf16_mfma>(b, level, xb, wb, stream) : dispatch_k64<f16_mfma>(b, level, xb, wb, stream);
+        if (rc != SBG_OK) return rc;
+        unsigned grid = (unsigned)((y_numel + 15) / 16); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)workspace, (float*)y, y_numel, k, acc);
+        SBG_HIP_LAUNCH_CHECK();
+        return SBG_OK;
+    }
     if (bf16) return dispatch_k64<bf16_mfma>(a, level, xb, wb, stream);
     return dispatch_k64<f16_mfma>(a, level, xb, wb, stream);
 }

@@ -206,6 +206,13 @@ def test_conv2d_double_backward(dev):
     _conv_case(dev, torch.float32, 2, 8, 16, 4, 4, 3, 2, 0, True, second_order=True)
 
 
+def test_conv2d_split_k(dev):
+    """few output tiles, long reduction: the gather kernel splits K over workgroups and a second kernel sums the fp32 slabs"""
+    _conv_case(dev, torch.float32, 8, 512, 520, 4, 4, 3, 1, 1, False)        # the 4x4 block: 6 folded passes -> K = 9 x 3072
+    _conv_case(dev, torch.float32, 2, 264, 136, 8, 8, 3, 1, 1, False)
+    _conv_case(dev, torch.float32, 4, 128, 128, 4, 4, 3, 2, 0, True)         # transposed phases write strided outputs: no split
+
+
 def test_conv2d_large_k_and_many_pixels(dev):
     # enough pixels that the weight-gradient kernel splits the pixel axis across workgroups
     _conv_case(dev, torch.bfloat16, 4, 64, 64, 64, 64, 3, 1, 1, False)
