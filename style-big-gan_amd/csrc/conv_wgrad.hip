@@ -348,14 +348,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
     }
 }
 
-// out[i] (+)= sum_s ws[s][i], fixed order.
+// out[i] (+)= sum_s ws[s][i], fixed order.  LANES lanes share an output element (slabs s, s + LANES, ...) and finish with a
+// shuffle tree, so a small output with many slabs (the fromrgb layer: 1024 elements x 1024 slabs) is not one serial chain per lane.
+template <int LANES>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* out, int64_t n, int nsplit, int accumulate)
 {
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
-        float s = accumulate ? out[i] : 0.f;
-        for (int k = 0; k < nsplit; k++) s += ws[(int64_t)k * n + i];
-        out[i] = s;
+    const int sub = threadIdx.x % LANES;
+    const int64_t step = (int64_t)gridDim.x * (256 / LANES);
+    for (int64_t i = (int64_t)blockIdx.x * (256 / LANES) + threadIdx.x / LANES; i < n; i += step) {
+        float s = 0.f;
+        int k = sub;
+        for (; k + 7 * LANES < nsplit; k += 8 * LANES) {         // eight independent loads in flight; the sum keeps its fixed order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = ws[(int64_t)(k + u * LANES) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; k < nsplit; k += LANES) s += ws[(int64_t)k * n + i];
+#pragma unroll
+        for (int m = LANES >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (sub == 0) out[i] = accumulate ? out[i] + s : s;
     }
 }
 
@@ -508,7 +521,12 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
     }
     if (a.nsplit > 1) {
         SbgProfScope prof(s, SBG_K_WGRAD_REDUCE, 0.0, 4.0 * out_n * (a.nsplit + 1), {(int)out_n, a.nsplit});
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(sbg_stream_grid(out_n, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
+        if (out_n >= (1 << 18) || a.nsplit < 16)      // plenty of elements: one lane each, coalesced across lanes
+            hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(sbg_stream_grid(out_n, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
+        else if (out_n >= (1 << 14))
+            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(sbg_stream_grid(out_n * 4, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(sbg_stream_grid(out_n * 64, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
         SBG_HIP_LAUNCH_CHECK();
     }
     return SBG_OK;
