@@ -1,2 +1,2 @@
-python -m pytest tests -m gpu -x -q -k "conv" 2>&1 | tail -2
-timeout -k 10 400 python bench.py --no-cpu-baseline --kernel-breakdown > gpurun_out/s16_bench.json 2> gpurun_out/s16_bench_breakdown.log; cat gpurun_out/s16_bench.json | cut -c1-330; grep -A5 '"wgrad_reduce"' gpurun_out/s16_bench_breakdown.log | head -6
+python -m pytest tests -m gpu -x -q -k "conv or networks or modconv" 2>&1 | tail -2
+timeout -k 10 400 python bench.py --no-cpu-baseline > gpurun_out/s18_bench.json 2>/dev/null; cat gpurun_out/s18_bench.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['target_kernel'])"

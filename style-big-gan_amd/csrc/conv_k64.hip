@@ -50,6 +50,77 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt_const() { asm
 // Straight-line fast path: the output dtype and "no epilogue math" are template parameters, every 8-channel group of the
 // wave is in range and 16-B aligned (checked by the caller), so the loops below carry no per-element guards and no dtype
 // branches: leaky ReLU with alpha 0 / 1 covers ReLU / linear, clamp = med3 with an infinite bound when disabled.
+template <int TC, int TP, int YDT, bool PLAIN, bool NUNI, class PixFn>
+static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix)
+{
+    // NUNI: every pixel of the wave lies in one image (halo kernel), so the demodulation coefficients are per-h constants.
+    constexpr int TH2 = TC / 2;
+    const float alpha = (p.act == SBG_ACT_LRELU) ? p.alpha : (p.act == SBG_ACT_RELU ? 0.f : 1.f);
+    const float cl = p.clamp >= 0.f ? p.clamp : __builtin_inff();
+    const float gain = p.gain;
+    int64_t yoff[TP]; float nz[TP]; bool ok[TP]; int nn[TP];
+#pragma unroll
+    for (int j = 0; j < TP; j++) {
+        int n, oy, ox;
+        ok[j] = pix(j, n, oy, ox);
+        nn[j] = n;
+        yoff[j] = (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
+        nz[j] = 0.f;
+        if (!PLAIN && p.noise && ok[j]) nz[j] = p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox];
+    }
+#pragma unroll
+    for (int h = 0; h < TH2; h++) {
+        float4_t b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo, s_lo = {1.f, 1.f, 1.f, 1.f}, s_hi = s_lo;
+        if (!PLAIN) {
+            if (p.bias) {
+                const float* b = p.bias + cbase + 32 * h + 8 * fg;
+                b_lo = *reinterpret_cast<const float4_t*>(b); b_hi = *reinterpret_cast<const float4_t*>(b + 4);
+            }
+            if (NUNI && p.oscale) {
+                const float* sc = p.oscale + (int64_t)nn[0] * p.Cout + cbase + 32 * h + 8 * fg;
+                s_lo = *reinterpret_cast<const float4_t*>(sc); s_hi = *reinterpret_cast<const float4_t*>(sc + 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TP; j++) {
+            if (!ok[j]) continue;
+            float4_t lo = acc[2 * h][j], hi = acc[2 * h + 1][j];
+            if (!PLAIN) {
+                if (!NUNI && p.oscale) {
+                    const float* sc = p.oscale + (int64_t)nn[j] * p.Cout + cbase + 32 * h + 8 * fg;
+                    s_lo = *reinterpret_cast<const float4_t*>(sc); s_hi = *reinterpret_cast<const float4_t*>(sc + 4);
+                }
+                lo = lo * s_lo + (nz[j] + b_lo);
+                hi = hi * s_hi + (nz[j] + b_hi);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float u = lo[e]; u = (u > 0.f) ? u : u * alpha; lo[e] = __builtin_amdgcn_fmed3f(u * gain, -cl, cl);
+                    float w = hi[e]; w = (w > 0.f) ? w : w * alpha; hi[e] = __builtin_amdgcn_fmed3f(w * gain, -cl, cl);
+                }
+            }
+            if (YDT == SBG_F32) {
+                float* dst = (float*)p.y + yoff[j] + 32 * h;
+                if (p.accumulate) { lo += *reinterpret_cast<float4_t*>(dst); hi += *reinterpret_cast<float4_t*>(dst + 4); }
+                *reinterpret_cast<float4_t*>(dst) = lo;
+                *reinterpret_cast<float4_t*>(dst + 4) = hi;
+            } else {
+                short8_t o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { o[e] = (short)f32_to_bf16_bits(lo[e]); o[4 + e] = (short)f32_to_bf16_bits(hi[e]); }
+                *reinterpret_cast<short8_t*>((unsigned short*)p.y + yoff[j] + 32 * h) = o;
+            }
+        }
+    }
+}
+
+// Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
+// e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
+// Fast path (Cout % 8 == 0, 16-B aligned output rows and per-channel vectors): no per-element guards, branch-free
+// activation (leaky ReLU with alpha 0 / 1 covers ReLU / linear; clamp = med3 with an infinite bound when disabled), one
+// 16-B store per 8 channels.  Everything else takes the guarded element-wise path.
+// Straight-line fast path: the output dtype and "no epilogue math" are template parameters, every 8-channel group of the
+// wave is in range and 16-B aligned (checked by the caller), so the loops below carry no per-element guards and no dtype
+// branches: leaky ReLU with alpha 0 / 1 covers ReLU / linear, clamp = med3 with an infinite bound when disabled.
 template <int TC, int TP, int YDT, bool PLAIN, class PixFn>
 static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix)
 {
@@ -110,7 +181,7 @@ static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, flo
 
 // Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
 // e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
-template <int TC, int TP, class PixFn>
+template <int TC, int TP, bool NUNI = false, class PixFn>
 static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix)
 {
     constexpr int TH2 = TC / 2;
@@ -120,11 +191,11 @@ static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_
                       && ((((uintptr_t)p.oscale) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && p.ydtype != SBG_F16;
     if (fast) {
         if (p.ydtype == SBG_BF16) {
-            if (plain) conv_epilogue_fast<TC, TP, SBG_BF16, true>(p, acc, cbase, fg, pix);
-            else       conv_epilogue_fast<TC, TP, SBG_BF16, false>(p, acc, cbase, fg, pix);
+            if (plain) conv_epilogue_fast<TC, TP, SBG_BF16, true, NUNI>(p, acc, cbase, fg, pix);
+            else       conv_epilogue_fast<TC, TP, SBG_BF16, false, NUNI>(p, acc, cbase, fg, pix);
         } else {
-            if (plain) conv_epilogue_fast<TC, TP, SBG_F32, true>(p, acc, cbase, fg, pix);
-            else       conv_epilogue_fast<TC, TP, SBG_F32, false>(p, acc, cbase, fg, pix);
+            if (plain) conv_epilogue_fast<TC, TP, SBG_F32, true, NUNI>(p, acc, cbase, fg, pix);
+            else       conv_epilogue_fast<TC, TP, SBG_F32, false, NUNI>(p, acc, cbase, fg, pix);
         }
         return;
     }
@@ -556,7 +627,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         par ^= 1;
         if (++chunk < kchunks) continue;
         if (!(dbg & 8))
-        conv_epilogue8<TC, TP>(p, acc, cur.c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
+        conv_epilogue8<TC, TP, true>(p, acc, cur.c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
             const int sg = wpi * TP + j, r = sg / SEG, cseg = (sg - r * SEG) * 16;
             n = cur.tn; oy = cur.y0 + r; ox = cur.x0 + cseg + fr;
             return true;
