@@ -590,6 +590,23 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
     }
     int stage = 0, par = 0, chunk = 0, tile = bid;
     TileC cur = decode(tile);
+    // The epilogue of a finished tile is deferred into the first step of the next tile, behind that step's B_a: there it runs
+    // beside the partner group's MFMA phase instead of holding both groups at a barrier (the stores are the exposed part of a
+    // short-K tile: 18 K-steps at Cin = 128).
+    bool pend = false;
+    TileC done = cur;
+    auto epilogue = [&](const TileC& tc) __attribute__((always_inline)) {
+        if (!(dbg & 8))
+        conv_epilogue8<TC, TP, true>(p, acc, tc.c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
+            const int sg = wpi * TP + j, r = sg / SEG, cseg = (sg - r * SEG) * 16;
+            n = tc.tn; oy = tc.y0 + r; ox = tc.x0 + cseg + fr;
+            return true;
+        });
+#pragma unroll
+        for (int i = 0; i < TC; i++)
+#pragma unroll
+            for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    };
     if (grpY) __builtin_amdgcn_s_barrier();              // 0
     for (int c = 0; c < nslices; c++) {
         const unsigned char* hb = sH + par * HALO_BYTES;
@@ -598,6 +615,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             const int shift = __builtin_amdgcn_readlane(tbl_shift, t);
             const unsigned char* sa = smem + stage * STAGE + wc * 128;
             __builtin_amdgcn_s_barrier();                // B_a: the stage and the halo buffer of this step have landed
+            if (t == 0 && pend) { epilogue(done); pend = false; }
             if (!(dbg & 4)) {
 #pragma unroll
             for (int ks = 0; ks < 2; ks++)
@@ -626,19 +644,11 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         });
         par ^= 1;
         if (++chunk < kchunks) continue;
-        if (!(dbg & 8))
-        conv_epilogue8<TC, TP, true>(p, acc, cur.c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
-            const int sg = wpi * TP + j, r = sg / SEG, cseg = (sg - r * SEG) * 16;
-            n = cur.tn; oy = cur.y0 + r; ox = cur.x0 + cseg + fr;
-            return true;
-        });
-#pragma unroll
-        for (int i = 0; i < TC; i++)
-#pragma unroll
-            for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+        pend = true; done = cur;
         chunk = 0; tile += G;
         if (tile < ntiles) cur = decode(tile);
     }
+    if (pend) epilogue(done);
     if (!grpY) __builtin_amdgcn_s_barrier();             // 2S
 }
 
