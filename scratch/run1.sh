@@ -1,2 +1,3 @@
+timeout -k 10 120 python scratch/k64_check.py 2>&1 | tail -1
 python -m pytest tests -m gpu -x -q -k "conv or networks or modconv" 2>&1 | tail -2
-timeout -k 10 400 python bench.py --no-cpu-baseline > gpurun_out/s18_bench.json 2>/dev/null; cat gpurun_out/s18_bench.json | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['target_kernel'])"
+for v in 0 1; do echo "== GATHER_LD=$v"; SBG_K64_GATHER_LD=$v timeout -k 10 120 python scratch/kbench.py conv 2>&1 | grep "s2\|convT"; done

@@ -652,6 +652,212 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
     if (!grpY) __builtin_amdgcn_s_barrier();             // 2S
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Gather kernel with loader waves: the 128 x 256 tile of conv_k64_kernel in the persistent 12-wave structure of
+// conv_halo_ld_kernel.  Waves 8-9 stream the weight tile, waves 10-11 gather the 256 pixel rows of the tap (im2col on the
+// fly, out-of-image rows at an out-of-range offset); three 48 KB stages, the loads of step s + 2 are issued while step s
+// computes.  Tiles bid, bid + G, ... run through one pipeline, the epilogue of a tile is deferred into the next tile's first
+// step.  Transposed-convolution phases and strided convolutions have 2-36 K-steps per tile, so the per-tile prologue /
+// epilogue of the one-tile-per-workgroup kernel was a third of their time.
+// Barrier indices as in conv_halo_ld_kernel; every loader: per step { wait step s landed; 2s; issue step s + 2 into the stage
+// step s - 1 used (its reads retired before 2s); 2s + 1 }, final 2S.
+template <class MF>
+__global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsigned x_bytes, unsigned w_bytes)
+{
+    constexpr int BC = 128, BP = 256, WGP = 4;
+    constexpr int WC = 64, WP = 64, TC = 4, TP = 4;
+    constexpr int NSTAGE = 3, A_BYTES = BC * 128, B_BYTES = BP * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int WPIECES = BC / 8 / 2;                // weight pieces per weight loader per step (8)
+    constexpr int XPIECES = BP / 8 / 2;                // pixel pieces per pixel loader per step (16)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {   // XCD-aware tile order: workgroups b and b + 8 share an XCD (L2); give each XCD a contiguous run of tiles
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int ntiles = p.ptiles * p.ctiles, G = gridDim.x;
+    const int my_tiles = (ntiles - bid + G - 1) / G;                  // tiles bid, bid + G, ...  (the grid never exceeds ntiles)
+    const int kchunks = (p.Cin + 63) >> 6;
+    const int nsteps = p.ntaps * kchunks;                              // K-steps per tile, tap-major: step = t * kchunks + chunk
+    const int S = my_tiles * nsteps;
+    const int lrow = lane >> 3;
+    const int src_k = ((lane & 7) ^ lrow) * 8;          // DMA lane -> (row = 8 piece + lrow, slot = lane & 7), source k-slot = slot ^ (row & 7)
+    const int tl = lane < p.ntaps ? lane : 0;
+
+    if (wave >= 8) {
+        // ---------------------------------------------------------------- loader waves -----------------------------------
+        const bool xload = wave >= 10;                  // waves 10, 11 gather pixels; 8, 9 stream weights
+        const int lw = (wave - 8) & 1;
+        __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)w_bytes, 0x00020000);
+        const int tbl_dy = p.tap_dy[tl], tbl_dx = p.tap_dx[tl];
+        const int tbl_wtap = p.tap_slab[tl] * (int)p.ws_slab * 2;
+        unsigned a_base[WPIECES];
+        int b_iy0[XPIECES], b_ix0[XPIECES]; unsigned b_base[XPIECES];
+        auto tile_state = [&](int tile) {
+            const int c0 = (tile % p.ctiles) * BC, p0 = (tile / p.ctiles) * BP;
+            if (!xload) {
+#pragma unroll
+                for (int i = 0; i < WPIECES; i++) {
+                    const int co = c0 + chmap((lw * WPIECES + i) * 8 + lrow);
+                    a_base[i] = (co < p.Cout) ? (unsigned)(co * (int)p.ws_co + src_k) * 2u : SBG_OOB_OFFSET;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < XPIECES; i++) {
+                    const int pix = p0 + (lw * XPIECES + i) * 8 + lrow;
+                    const bool ok = pix < p.P;
+                    const int pp = ok ? pix : 0;
+                    const int ox = pp % p.OW, t = pp / p.OW, oy = t % p.OH, n = t / p.OH;
+                    b_iy0[i] = ok ? oy * p.stride : -(1 << 28);            // invalid rows fail every range test below
+                    b_ix0[i] = ox * p.stride;
+                    b_base[i] = (unsigned)(n * (int)p.xs_n + src_k) * 2u;
+                }
+            }
+        };
+        // (it, ic, itile, istage): coordinates of the step whose loads are issued next
+        int it = 0, ic = 0, itile = bid, istage = 0;
+        tile_state(itile);
+        auto issue_next = [&]() {
+            const unsigned kokm = 0u - (unsigned)(ic * 64 + src_k < p.Cin);
+            if (!xload) {
+                unsigned char* st = smem + istage * STAGE + lw * WPIECES * 1024;
+                const unsigned wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, it) + ic * 128);
+#pragma unroll
+                for (int i = 0; i < WPIECES; i++) {
+                    const unsigned okm = kokm & (0u - (unsigned)(a_base[i] != SBG_OOB_OFFSET));      // branch-free: a masked-off lane would leave stale LDS bytes
+                    const unsigned off = ((a_base[i] + wtap) & okm) | (SBG_OOB_OFFSET & ~okm);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + i * 1024), 16, off, 0, 0, 0);
+                }
+            } else {
+                unsigned char* st = smem + istage * STAGE + A_BYTES + lw * XPIECES * 1024;
+                const int dy = __builtin_amdgcn_readlane(tbl_dy, it), dx = __builtin_amdgcn_readlane(tbl_dx, it);
+#pragma unroll
+                for (int i = 0; i < XPIECES; i++) {
+                    const int iy = b_iy0[i] + dy, ix = b_ix0[i] + dx;
+                    const unsigned okm = kokm & (0u - (unsigned)(((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW)));
+                    const unsigned real = b_base[i] + (unsigned)(iy * (int)p.xs_h + ix * (int)p.xs_w + ic * 64) * 2u;
+                    const unsigned off = (real & okm) | (SBG_OOB_OFFSET & ~okm);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(st + i * 1024), 16, off, 0, 0, 0);
+                }
+            }
+            istage = istage == NSTAGE - 1 ? 0 : istage + 1;
+            if (++ic == kchunks) {
+                ic = 0;
+                if (++it == p.ntaps) { it = 0; itile += G; if (itile < ntiles) tile_state(itile); }
+            }
+        };
+        int issued = 0;                                  // steps issued so far
+        for (; issued < NSTAGE && issued < S; issued++) issue_next();
+        for (int s = 0; s < S; s++) {
+            // step s has landed once at most the steps issued after it are outstanding (same instruction count per step)
+            const int newer = issued - 1 - s;            // 0 .. 2
+            if (xload) {
+                if (newer >= 2) wait_vmcnt_const<2 * XPIECES>(); else if (newer == 1) wait_vmcnt_const<XPIECES>(); else wait_vmcnt_const<0>();
+            } else {
+                if (newer >= 2) wait_vmcnt_const<2 * WPIECES>(); else if (newer == 1) wait_vmcnt_const<WPIECES>(); else wait_vmcnt_const<0>();
+            }
+            __builtin_amdgcn_s_barrier();                // 2s
+            if (s >= 1 && issued < S) { issue_next(); issued++; }     // step s + 2 -> the stage step s - 1 was read from
+            __builtin_amdgcn_s_barrier();                // 2s + 1
+        }
+        __builtin_amdgcn_s_barrier();                    // 2S
+        return;
+    }
+
+    // -------------------------------------------------------------------- compute waves (0-7) ----------------------------
+    const bool grpY = wave >= 4;
+    const int wci = wave >> 2, wpi = wave & 3;
+    const int wc = wci * WC, wp = wpi * WP;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int frag_off = fr * 128 + ((fg ^ (fr & 7)) << 4);          // k-sub 0; k-sub 1 = ^ 64
+    float4_t acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; i++)
+#pragma unroll
+        for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    short8_t fa[2][TC], fb[2][TP];
+    int stage = 0, tile = bid, left = nsteps;            // steps left in the tile being computed
+    bool pend = false;
+    int done_tile = tile;
+    auto epilogue = [&](int t_) __attribute__((always_inline)) {
+        const int c0 = (t_ % p.ctiles) * BC, p0 = (t_ / p.ctiles) * BP;
+        conv_epilogue8<TC, TP>(p, acc, c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
+            const int pix = p0 + wp + 16 * j + fr;
+            const int pp = pix < p.P ? pix : 0;
+            ox = pp % p.OW; const int t = pp / p.OW; oy = t % p.OH; n = t / p.OH;
+            return pix < p.P;
+        });
+#pragma unroll
+        for (int i = 0; i < TC; i++)
+#pragma unroll
+            for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    if (grpY) __builtin_amdgcn_s_barrier();              // 0
+    for (int s = 0; s < S; s++) {
+        const unsigned char* sa = smem + stage * STAGE + wc * 128;
+        const unsigned char* sb = smem + stage * STAGE + A_BYTES + wp * 128;
+        __builtin_amdgcn_s_barrier();                    // B_a: the stage of this step has landed
+        if (pend) { epilogue(done_tile); pend = false; } // previous tile's stores run beside the partner group's MFMA phase
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < TC; i++) fa[ks][i] = *reinterpret_cast<const short8_t*>(sa + i * 16 * 128 + (frag_off ^ (ks * 64)));
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int j = 0; j < TP; j++) fb[ks][j] = *reinterpret_cast<const short8_t*>(sb + j * 16 * 128 + (frag_off ^ (ks * 64)));
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): fragments are in registers, this wave no longer reads the stage
+        __builtin_amdgcn_s_barrier();                    // B_b
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < TC; i++)
+#pragma unroll
+                for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[ks][i], fb[ks][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        if (--left == 0) { pend = true; done_tile = tile; tile += G; left = nsteps; }
+    }
+    if (pend) epilogue(done_tile);
+    if (!grpY) __builtin_amdgcn_s_barrier();             // 2S
+}
+
+template <class MF>
+static int launch_gather_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
+{
+    constexpr int lds = 3 * (128 * 128 + 256 * 128);
+    a.ctiles = (a.Cout + 127) / 128;
+    a.ptiles = (a.P + 255) / 256;
+    int64_t nblk = (int64_t)a.ptiles * a.ctiles;
+    if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        ncu = n;
+    }
+    if (nblk > ncu) nblk = ncu;     // persistent: one workgroup per CU, each walks tiles b, b + grid, ...
+    auto kern = conv_gather_ld_kernel<MF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
+        attr_set = true;
+    }
+    const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
+    SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
+                      2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
+                      {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 4128256});
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(768), lds, stream, a, x_bytes, w_bytes);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
+
 template <class MF, int TH, int TW>
 static int launch_halo_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
 {
@@ -737,6 +943,11 @@ static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStr
     if (a.Cout <= 64) return launch_k64<MF, 64, 256, 1, 8>(a, xb, wb, stream);
     if (a.ksplit > 1) return launch_k64<MF, 128, 128, 2, 4>(a, xb, wb, stream);        // the caller wraps this launch with the slab reduction
     if (tiles256 < 256) return launch_k64<MF, 128, 128, 2, 4>(a, xb, wb, stream);
+    // short reductions (transposed-conv phases: 1-4 taps) gain from the persistent pipeline; measured: +4..10 % at <= 8 K-steps per tile,
+    // -5 % at 18+ (the 8-wave kernel's in-wave DMA issue overlaps better there)
+    static const char* egl = getenv("SBG_K64_GATHER_LD");        // experiment switch: 0 never, 1 always
+    const int ksteps = a.ntaps * ((a.Cin + 63) >> 6);
+    if (egl ? atoi(egl) != 0 : ksteps <= 8) return launch_gather_ld<MF>(a, xb, wb, stream);
     return launch_k64<MF, 128, 256, 2, 4>(a, xb, wb, stream);
 }
 
