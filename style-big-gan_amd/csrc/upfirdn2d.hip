@@ -167,6 +167,75 @@ __global__ __launch_bounds__(256) void upfirdn2d_fir_kernel(UpfirdnArgs p, int x
     }
 }
 
+// The register-blocked kernel with the filter size known at compile time (4 x 4: the [1, 3, 3, 1] low-pass of every up / down
+// layer): the window loops unroll, the taps live in registers and the tap-range tests fold away.  The bounds tests stay branches
+// around each load, which also keeps the loads in program order (bounded live set).
+template <class T, int FH, int FW>
+__global__ __launch_bounds__(256) void upfirdn2d_fir_fixed_kernel(UpfirdnArgs p, int xblocks, int yblocks)
+{
+    float fv[FH][FW];                                   // visiting order: fv[ky][kx] multiplies the window pixel (.. + ky, .. + kx)
+#pragma unroll
+    for (int ky = 0; ky < FH; ky++)
+#pragma unroll
+        for (int kx = 0; kx < FW; kx++) {
+            const int fy = p.flip ? ky : FH - 1 - ky, fx = p.flip ? kx : FW - 1 - kx;
+            fv[ky][kx] = p.f[fy * p.fsy + fx * p.fsx] * p.gain;
+        }
+    const T* px = (const T*)p.x; T* py = (T*)p.y;
+    const int cvecs = p.C >> 3;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < p.total; idx += step) {
+        int64_t r = idx;
+        const int c = (int)(r % cvecs) << 3; r /= cvecs;
+        const int xb = (int)(r % xblocks); r /= xblocks;
+        const int yb = (int)(r % yblocks); const int n = (int)(r / yblocks);
+        const int ox0 = xb * FIR_TX, oy0 = yb * FIR_TY;
+        float acc[FIR_TY][FIR_TX][8];
+#pragma unroll
+        for (int a = 0; a < FIR_TY; a++)
+#pragma unroll
+            for (int b = 0; b < FIR_TX; b++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[a][b][e] = 0.f;
+        const T* xin = px + n * p.isn + c;
+#pragma unroll
+        for (int wy = 0; wy < FIR_TY + FH - 1; wy++) {
+            const int iy = oy0 + wy - p.pady0;
+            if ((unsigned)iy >= (unsigned)p.inH) continue;
+#pragma unroll
+            for (int wx = 0; wx < FIR_TX + FW - 1; wx++) {
+                const int ix = ox0 + wx - p.padx0;
+                if ((unsigned)ix >= (unsigned)p.inW) continue;
+                float v[8];
+                Vec8<T>::ld(xin + iy * p.isy + ix * p.isx, v);
+#pragma unroll
+                for (int a = 0; a < FIR_TY; a++) {
+                    const int ky = wy - a;
+                    if (ky < 0 || ky >= FH) continue;
+#pragma unroll
+                    for (int b = 0; b < FIR_TX; b++) {
+                        const int kx = wx - b;
+                        if (kx < 0 || kx >= FW) continue;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) acc[a][b][e] += v[e] * fv[ky][kx];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < FIR_TY; a++) {
+            const int oy = oy0 + a;
+            if (oy >= p.outH) continue;
+#pragma unroll
+            for (int b = 0; b < FIR_TX; b++) {
+                const int ox = ox0 + b;
+                if (ox >= p.outW) continue;
+                Vec8<T>::st(py + n * p.osn + c + oy * p.osy + ox * p.osx, acc[a][b]);
+            }
+        }
+    }
+}
+
 template <class T>
 static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, hipStream_t stream)
 {
@@ -178,7 +247,10 @@ static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, hipStream_t stream)
     if (vec8 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw <= FIR_MAXF && a.fh <= FIR_MAXF && a.fw * a.fh > 1) {
         const int xblocks = (a.outW + FIR_TX - 1) / FIR_TX, yblocks = (a.outH + FIR_TY - 1) / FIR_TY;
         a.total = (int64_t)a.N * yblocks * xblocks * (a.C >> 3);
-        hipLaunchKernelGGL((upfirdn2d_fir_kernel<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a, xblocks, yblocks);
+        if (a.fw == 4 && a.fh == 4)
+            hipLaunchKernelGGL((upfirdn2d_fir_fixed_kernel<T, 4, 4>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a, xblocks, yblocks);
+        else
+            hipLaunchKernelGGL((upfirdn2d_fir_kernel<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a, xblocks, yblocks);
     } else if (vec8) {
         a.total = (int64_t)a.N * a.outH * a.outW * (a.C >> 3);
         hipLaunchKernelGGL((upfirdn2d_kernel<T, 8>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a);
