@@ -113,6 +113,11 @@ typedef struct sbg_conv_params {
      * (>= sbg_conv2d_igemm_workspace() bytes) and a second kernel sums them in a fixed order into y (bitwise reproducible).
      * Needs a dense fp32 y without fused epilogue; ksplit <= 1 or workspace == NULL = off. */
     void* workspace; int ksplit;
+    /* Optional phases: nphase in 2..4 makes ONE launch compute several output sub-grids of the same input -- the s x s phases of a
+     * stride-s transposed convolution, whose tiles then share the input through L2 instead of streaming it from HBM once per phase.
+     * Phase i uses the next ph_ntaps[i] taps of the tap list (sum <= ntaps), the output grid ph_oh[i] x ph_ow[i] (instead of OH x OW)
+     * and writes at y + ph_yoff[i] elements with the common ys_* strides.  nphase <= 1 = off.  No fused epilogue / split with phases. */
+    int nphase; int ph_ntaps[4], ph_oh[4], ph_ow[4]; int64_t ph_yoff[4];
 } sbg_conv_params;
 int64_t sbg_conv2d_igemm_workspace(const sbg_conv_params* p);
 int     sbg_conv2d_igemm(const sbg_conv_params* p, sbg_stream_t stream);

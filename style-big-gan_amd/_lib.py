@@ -52,6 +52,7 @@ class ConvParams(ctypes.Structure):
         ("bias", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("noise_stride_n", ctypes.c_int64),
         ("act", ctypes.c_int), ("alpha", ctypes.c_float), ("gain", ctypes.c_float), ("clamp", ctypes.c_float),
         ("workspace", ctypes.c_void_p), ("ksplit", ctypes.c_int),
+        ("nphase", ctypes.c_int), ("ph_ntaps", ctypes.c_int * 4), ("ph_oh", ctypes.c_int * 4), ("ph_ow", ctypes.c_int * 4), ("ph_yoff", ctypes.c_int64 * 4),
     ]
 
 

@@ -32,6 +32,11 @@ struct ConvArgs {
     int accumulate;
     int P;            // N * OH * OW output pixels of this launch
     int ptiles, ctiles;
+    // phases (conv_gather_ld_kernel): up to four output sub-grids of one launch (the s x s phases of a transposed convolution), each
+    // with its own run of taps [ph_tap0, ph_tap0 + ph_ntaps), grid ph_OH x ph_OW, pixel count ph_P and y offset; nphase == 1: the whole launch
+    int nphase, ph_rot_div;   // phase of tile r = (r % nphase + (r / nphase) / ph_rot_div) % nphase: a persistent workgroup cycles through the phases
+    int ph_tap0[4], ph_ntaps[4], ph_OH[4], ph_OW[4], ph_P[4];
+    int64_t ph_yoff[4];
     int ksplit;               // gather kernel: the K-steps are split over gridDim.y workgroups, each writing its own fp32 slab
     int64_t y_split_stride;   // elements between the slabs (0 when ksplit == 1)
     int debug;        // ablation switches, honoured only by -DSBG_K64_DEBUG builds (diagnosis; see conv_k64.hip)

@@ -433,12 +433,44 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     for (int t = 0; t < SBG_MAX_TAPS; t++) { a.tap_dy[t] = q->tap_dy[t]; a.tap_dx[t] = q->tap_dx[t]; a.tap_slab[t] = q->tap_slab[t]; }
     a.accumulate = q->accumulate;
     a.P = (int)P; a.ptiles = a.ctiles = 0; a.debug = 0; a.ksplit = 1; a.y_split_stride = 0;
+    a.nphase = 1; a.ph_rot_div = 1;
+    for (int i = 0; i < 4; i++) { a.ph_tap0[i] = 0; a.ph_ntaps[i] = 0; a.ph_OH[i] = 0; a.ph_OW[i] = 0; a.ph_P[i] = 0; a.ph_yoff[i] = 0; }
     hipStream_t s = (hipStream_t)stream;
     int maxslab = 0;
     for (int t = 0; t < q->ntaps; t++) { SBG_CHECK(q->tap_slab[t] >= 0, "conv2d_igemm: negative weight slab"); if (q->tap_slab[t] > maxslab) maxslab = q->tap_slab[t]; }
     const int64_t x_bytes = 2 * ((int64_t)(q->N - 1) * q->xs_n + (int64_t)(q->IH - 1) * q->xs_h + (int64_t)(q->IW - 1) * q->xs_w + q->Cin);
     const int64_t w_bytes = 2 * ((int64_t)maxslab * q->ws_slab + (int64_t)(q->Cout - 1) * q->ws_co + q->Cin);
     const bool allow_dma = getenv("SBG_CONV_NO_DMA") == nullptr && q->xs_n >= 0 && q->xs_h >= 0 && q->xs_w >= 0 && q->ws_slab >= 0 && q->ws_co >= 0;
+    if (q->nphase > 1) {
+        // phases: one persistent launch when the shape fits that kernel, otherwise one launch per phase through this same entry point
+        SBG_CHECK(q->nphase <= 4, "conv2d_igemm: at most 4 phases");
+        const bool plain = (q->act == 0 || q->act == SBG_ACT_LINEAR) && (q->gain == 1.f || q->gain == 0.f) && q->clamp < 0.f && !q->bias && !q->noise && !q->oscale;
+        SBG_CHECK(plain && (q->ksplit <= 1), "conv2d_igemm: phases exclude the fused epilogue and the K split");
+        int t0 = 0; int64_t ptot = 0;
+        for (int i = 0; i < q->nphase; i++) {
+            SBG_CHECK(q->ph_ntaps[i] >= 1 && q->ph_oh[i] >= 1 && q->ph_ow[i] >= 1, "conv2d_igemm: bad phase %d", i);
+            a.ph_tap0[i] = t0; a.ph_ntaps[i] = q->ph_ntaps[i]; a.ph_OH[i] = q->ph_oh[i]; a.ph_OW[i] = q->ph_ow[i];
+            a.ph_P[i] = q->N * q->ph_oh[i] * q->ph_ow[i]; a.ph_yoff[i] = q->ph_yoff[i];
+            t0 += q->ph_ntaps[i]; ptot += a.ph_P[i];
+        }
+        SBG_CHECK(t0 <= q->ntaps, "conv2d_igemm: phases use %d taps, %d given", t0, q->ntaps);
+        const int64_t tiles = ((ptot / q->nphase + 255) / 256) * q->nphase * ((q->Cout + 127) / 128);
+        if (allow_dma && q->Cout > 64 && tiles >= 256 && x_bytes < (int64_t)0x80000000u && w_bytes < (int64_t)0x80000000u && getenv("SBG_CONV_NO_PHASES") == nullptr) {
+            a.nphase = q->nphase;
+            const int rc = sbg_conv_k64_dispatch(a, q->xdtype == SBG_BF16, x_bytes, w_bytes, nullptr, 1, s);
+            if (rc >= 0) return rc;
+            a.nphase = 1;
+        }
+        for (int i = 0; i < q->nphase; i++) {
+            sbg_conv_params one = *q;
+            one.nphase = 0; one.OH = q->ph_oh[i]; one.OW = q->ph_ow[i]; one.ntaps = q->ph_ntaps[i];
+            one.y = (char*)q->y + q->ph_yoff[i] * (q->ydtype == SBG_F32 ? 4 : 2);
+            for (int t = 0; t < one.ntaps; t++) { one.tap_dy[t] = q->tap_dy[a.ph_tap0[i] + t]; one.tap_dx[t] = q->tap_dx[a.ph_tap0[i] + t]; one.tap_slab[t] = q->tap_slab[a.ph_tap0[i] + t]; }
+            const int rc = sbg_conv2d_igemm(&one, stream);
+            if (rc != SBG_OK) return rc;
+        }
+        return SBG_OK;
+    }
     if (allow_dma) {      // K-step-64 kernels (conv_k64.hip) take every launch whose operands fit a 2 GiB buffer descriptor
         const int rc = sbg_conv_k64_dispatch(a, q->xdtype == SBG_BF16, x_bytes, w_bytes, q->workspace, q->ksplit, s);
         if (rc >= 0) return rc;

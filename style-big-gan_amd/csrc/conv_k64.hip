@@ -51,7 +51,7 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt_const() { asm
 // wave is in range and 16-B aligned (checked by the caller), so the loops below carry no per-element guards and no dtype
 // branches: leaky ReLU with alpha 0 / 1 covers ReLU / linear, clamp = med3 with an infinite bound when disabled.
 template <int TC, int TP, int YDT, bool PLAIN, bool NUNI, class PixFn>
-static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix)
+static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix, int64_t ybase)
 {
     // NUNI: every pixel of the wave lies in one image (halo kernel), so the demodulation coefficients are per-h constants.
     constexpr int TH2 = TC / 2;
@@ -64,7 +64,7 @@ static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, flo
         int n, oy, ox;
         ok[j] = pix(j, n, oy, ox);
         nn[j] = n;
-        yoff[j] = (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
+        yoff[j] = ybase + (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
         nz[j] = 0.f;
         if (!PLAIN && p.noise && ok[j]) nz[j] = p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox];
     }
@@ -182,7 +182,7 @@ static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, flo
 // Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
 // e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
 template <int TC, int TP, bool NUNI = false, class PixFn>
-static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix)
+static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix, int64_t ybase = 0)
 {
     constexpr int TH2 = TC / 2;
     const bool plain = (p.act <= SBG_ACT_LINEAR) && p.gain == 1.f && p.clamp < 0.f && !p.bias && !p.noise && !p.oscale;
@@ -191,11 +191,11 @@ static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_
                       && ((((uintptr_t)p.oscale) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && p.ydtype != SBG_F16;
     if (fast) {
         if (p.ydtype == SBG_BF16) {
-            if (plain) conv_epilogue_fast<TC, TP, SBG_BF16, true, NUNI>(p, acc, cbase, fg, pix);
-            else       conv_epilogue_fast<TC, TP, SBG_BF16, false, NUNI>(p, acc, cbase, fg, pix);
+            if (plain) conv_epilogue_fast<TC, TP, SBG_BF16, true, NUNI>(p, acc, cbase, fg, pix, ybase);
+            else       conv_epilogue_fast<TC, TP, SBG_BF16, false, NUNI>(p, acc, cbase, fg, pix, ybase);
         } else {
-            if (plain) conv_epilogue_fast<TC, TP, SBG_F32, true, NUNI>(p, acc, cbase, fg, pix);
-            else       conv_epilogue_fast<TC, TP, SBG_F32, false, NUNI>(p, acc, cbase, fg, pix);
+            if (plain) conv_epilogue_fast<TC, TP, SBG_F32, true, NUNI>(p, acc, cbase, fg, pix, ybase);
+            else       conv_epilogue_fast<TC, TP, SBG_F32, false, NUNI>(p, acc, cbase, fg, pix, ybase);
         }
         return;
     }
@@ -210,7 +210,7 @@ static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_
     for (int j = 0; j < TP; j++) {
         int n, oy, ox;
         if (!pix(j, n, oy, ox)) continue;
-        const int64_t yoff = (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
+        const int64_t yoff = ybase + (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
         const float nz = (!plain && p.noise) ? p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox] : 0.f;
 #pragma unroll
         for (int h = 0; h < TH2; h++) {
@@ -681,8 +681,13 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
     const int ntiles = p.ptiles * p.ctiles, G = gridDim.x;
     const int my_tiles = (ntiles - bid + G - 1) / G;                  // tiles bid, bid + G, ...  (the grid never exceeds ntiles)
     const int kchunks = (p.Cin + 63) >> 6;
-    const int nsteps = p.ntaps * kchunks;                              // K-steps per tile, tap-major: step = t * kchunks + chunk
-    const int S = my_tiles * nsteps;
+    // tile -> (channel tile, phase, pixel tile): the phases of one pixel tile are neighbours in the tile order, so they run at the same
+    // time on CUs of one XCD and share the input rows through its L2.  K-steps of a tile, tap-major: step = t * kchunks + chunk.
+    // The phases have different K lengths (4 / 2 / 2 / 1 taps), and tile + G keeps r % nphase, so the phase is rotated with the pixel
+    // tile: every workgroup then walks all phases in turn (equal work) -- still a bijection on (pixel tile, phase).
+    auto tile_phase = [&](int tile) { const int r = tile / p.ctiles; return (r % p.nphase + (r / p.nphase) / p.ph_rot_div) % p.nphase; };
+    int S = 0;
+    for (int t_ = bid; t_ < ntiles; t_ += G) S += p.ph_ntaps[tile_phase(t_)] * kchunks;
     const int lrow = lane >> 3;
     const int src_k = ((lane & 7) ^ lrow) * 8;          // DMA lane -> (row = 8 piece + lrow, slot = lane & 7), source k-slot = slot ^ (row & 7)
     const int tl = lane < p.ntaps ? lane : 0;
@@ -697,8 +702,12 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
         const int tbl_wtap = p.tap_slab[tl] * (int)p.ws_slab * 2;
         unsigned a_base[WPIECES];
         int b_iy0[XPIECES], b_ix0[XPIECES]; unsigned b_base[XPIECES];
+        int ph_t0 = 0, ph_nt = 1;                       // taps of the issue tile's phase
         auto tile_state = [&](int tile) {
-            const int c0 = (tile % p.ctiles) * BC, p0 = (tile / p.ctiles) * BP;
+            const int ph = tile_phase(tile);
+            const int c0 = (tile % p.ctiles) * BC, p0 = (tile / p.ctiles / p.nphase) * BP;
+            const int OW_ = p.ph_OW[ph], OH_ = p.ph_OH[ph], P_ = p.ph_P[ph];
+            ph_t0 = p.ph_tap0[ph]; ph_nt = p.ph_ntaps[ph];
             if (!xload) {
 #pragma unroll
                 for (int i = 0; i < WPIECES; i++) {
@@ -709,9 +718,9 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
 #pragma unroll
                 for (int i = 0; i < XPIECES; i++) {
                     const int pix = p0 + (lw * XPIECES + i) * 8 + lrow;
-                    const bool ok = pix < p.P;
+                    const bool ok = pix < P_;
                     const int pp = ok ? pix : 0;
-                    const int ox = pp % p.OW, t = pp / p.OW, oy = t % p.OH, n = t / p.OH;
+                    const int ox = pp % OW_, t = pp / OW_, oy = t % OH_, n = t / OH_;
                     b_iy0[i] = ok ? oy * p.stride : -(1 << 28);            // invalid rows fail every range test below
                     b_ix0[i] = ox * p.stride;
                     b_base[i] = (unsigned)(n * (int)p.xs_n + src_k) * 2u;
@@ -725,7 +734,7 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
             const unsigned kokm = 0u - (unsigned)(ic * 64 + src_k < p.Cin);
             if (!xload) {
                 unsigned char* st = smem + istage * STAGE + lw * WPIECES * 1024;
-                const unsigned wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, it) + ic * 128);
+                const unsigned wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, ph_t0 + it) + ic * 128);
 #pragma unroll
                 for (int i = 0; i < WPIECES; i++) {
                     const unsigned okm = kokm & (0u - (unsigned)(a_base[i] != SBG_OOB_OFFSET));      // branch-free: a masked-off lane would leave stale LDS bytes
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
                 }
             } else {
                 unsigned char* st = smem + istage * STAGE + A_BYTES + lw * XPIECES * 1024;
-                const int dy = __builtin_amdgcn_readlane(tbl_dy, it), dx = __builtin_amdgcn_readlane(tbl_dx, it);
+                const int dy = __builtin_amdgcn_readlane(tbl_dy, ph_t0 + it), dx = __builtin_amdgcn_readlane(tbl_dx, ph_t0 + it);
 #pragma unroll
                 for (int i = 0; i < XPIECES; i++) {
                     const int iy = b_iy0[i] + dy, ix = b_ix0[i] + dx;
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
             istage = istage == NSTAGE - 1 ? 0 : istage + 1;
             if (++ic == kchunks) {
                 ic = 0;
-                if (++it == p.ntaps) { it = 0; itile += G; if (itile < ntiles) tile_state(itile); }
+                if (++it == ph_nt) { it = 0; itile += G; if (itile < ntiles) tile_state(itile); }
             }
         };
         int issued = 0;                                  // steps issued so far
@@ -780,17 +789,19 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
 #pragma unroll
         for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
     short8_t fa[2][TC], fb[2][TP];
-    int stage = 0, tile = bid, left = nsteps;            // steps left in the tile being computed
+    int stage = 0, tile = bid, left = p.ph_ntaps[tile_phase(bid)] * kchunks;      // steps left in the tile being computed
     bool pend = false;
     int done_tile = tile;
     auto epilogue = [&](int t_) __attribute__((always_inline)) {
-        const int c0 = (t_ % p.ctiles) * BC, p0 = (t_ / p.ctiles) * BP;
+        const int ph = tile_phase(t_);
+        const int c0 = (t_ % p.ctiles) * BC, p0 = (t_ / p.ctiles / p.nphase) * BP;
+        const int OW_ = p.ph_OW[ph], OH_ = p.ph_OH[ph], P_ = p.ph_P[ph];
         conv_epilogue8<TC, TP>(p, acc, c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
             const int pix = p0 + wp + 16 * j + fr;
-            const int pp = pix < p.P ? pix : 0;
-            ox = pp % p.OW; const int t = pp / p.OW; oy = t % p.OH; n = t / p.OH;
-            return pix < p.P;
-        });
+            const int pp = pix < P_ ? pix : 0;
+            ox = pp % OW_; const int t = pp / OW_; oy = t % OH_; n = t / OH_;
+            return pix < P_;
+        }, p.ph_yoff[ph]);
 #pragma unroll
         for (int i = 0; i < TC; i++)
 #pragma unroll
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
                 for (int j = 0; j < TP; j++) acc[i][j] = Mfma<MF>::run(fa[ks][i], fb[ks][j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
         stage = stage == NSTAGE - 1 ? 0 : stage + 1;
-        if (--left == 0) { pend = true; done_tile = tile; tile += G; left = nsteps; }
+        if (--left == 0) { pend = true; done_tile = tile; tile += G; if (tile < ntiles) left = p.ph_ntaps[tile_phase(tile)] * kchunks; }
     }
     if (pend) epilogue(done_tile);
     if (!grpY) __builtin_amdgcn_s_barrier();             // 2S
@@ -832,7 +843,12 @@ static int launch_gather_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hip
 {
     constexpr int lds = 3 * (128 * 128 + 256 * 128);
     a.ctiles = (a.Cout + 127) / 128;
-    a.ptiles = (a.P + 255) / 256;
+    if (a.nphase <= 1) {            // the whole launch as one phase
+        a.nphase = 1; a.ph_tap0[0] = 0; a.ph_ntaps[0] = a.ntaps; a.ph_OH[0] = a.OH; a.ph_OW[0] = a.OW; a.ph_P[0] = a.P; a.ph_yoff[0] = 0;
+    }
+    int pmax = 0;
+    for (int i = 0; i < a.nphase; i++) if (a.ph_P[i] > pmax) pmax = a.ph_P[i];
+    a.ptiles = ((pmax + 255) / 256) * a.nphase;      // every phase gets the pixel tiles of the largest one (the others' last tile may be empty)
     int64_t nblk = (int64_t)a.ptiles * a.ctiles;
     if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
     static int ncu = 0;
@@ -842,6 +858,7 @@ static int launch_gather_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hip
         ncu = n;
     }
     if (nblk > ncu) nblk = ncu;     // persistent: one workgroup per CU, each walks tiles b, b + grid, ...
+    a.ph_rot_div = (int)(nblk / ((int64_t)a.ctiles * a.nphase)); if (a.ph_rot_div < 1) a.ph_rot_div = 1;
     auto kern = conv_gather_ld_kernel<MF>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -850,9 +867,11 @@ static int launch_gather_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hip
         attr_set = true;
     }
     const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
-    SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
-                      2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
-                      {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 4128256});
+    double macs = 0.0, outpix = 0.0;
+    for (int i = 0; i < a.nphase; i++) { macs += (double)a.ph_P[i] * a.ph_ntaps[i]; outpix += a.ph_P[i]; }
+    SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * macs * a.Cout * (double)a.Cin,
+                      2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * outpix * (double)a.Cout * (a.accumulate ? 2 : 1),
+                      {(int)outpix, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 4128256 + (a.nphase > 1 ? 1000000 * a.nphase : 0)});
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(768), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
@@ -932,6 +951,7 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* ws
 template <class MF>
 static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStream_t stream)
 {
+    if (a.nphase > 1) return launch_gather_ld<MF>(a, xb, wb, stream);       // multi-phase launches exist only in the persistent gather kernel
     // halo kernel: stride 1, nine taps with |offset| <= 1, output grid == input grid, tile-aligned, enough tiles to fill the chip
     bool halo = level >= 2 && a.stride == 1 && a.ntaps == 9 && a.OH == a.IH && a.OW == a.IW;
     for (int t = 0; halo && t < 9; t++) halo = a.tap_dy[t] >= -1 && a.tap_dy[t] <= 1 && a.tap_dx[t] >= -1 && a.tap_dx[t] <= 1;

@@ -164,6 +164,33 @@ def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=N
     _lib.check(lib.sbg_conv2d_igemm(p, _lib.stream_ptr(x.device)), "sbg_conv2d_igemm")
 
 
+def _igemm_phases(x, wp, y, phases, s):
+    """ONE launch for all phases of a stride-s transposed convolution (sbg_conv_params.nphase): phase (a, b) writes
+    y[:, :, a::s, b::s] from its own run of taps; the phases' tiles share the input through L2."""
+    lib = _lib.load()
+    p = _lib.ConvParams()
+    n, cin, ih, iw = x.shape
+    cout = wp.shape[1]
+    p.x, p.w, p.y = x.data_ptr(), wp.data_ptr(), y.data_ptr()
+    p.xdtype, p.ydtype = _lib.dtype_code(x.dtype), _lib.dtype_code(y.dtype)
+    p.N, p.IH, p.IW, p.Cin, p.Cout = n, ih, iw, cin, cout
+    p.OH, p.OW = max(ph[2] for ph in phases), max(ph[3] for ph in phases)
+    p.xs_n, p.xs_h, p.xs_w = x.stride(0), x.stride(2), x.stride(3)
+    p.ys_n, p.ys_h, p.ys_w = y.stride(0), y.stride(2) * s, y.stride(3) * s
+    p.ws_slab, p.ws_co = wp.stride(0), wp.stride(1)
+    p.stride = 1
+    p.act, p.alpha, p.gain, p.clamp = 1, 0.0, 1.0, -1.0
+    t = 0
+    for i, (a, b, goh, gow, taps) in enumerate(phases):
+        p.ph_ntaps[i], p.ph_oh[i], p.ph_ow[i] = len(taps), goh, gow
+        p.ph_yoff[i] = a * y.stride(2) + b * y.stride(3)
+        for dy, dx, slab in taps:
+            p.tap_dy[t], p.tap_dx[t], p.tap_slab[t] = dy, dx, slab
+            t += 1
+    p.ntaps, p.nphase = t, len(phases)
+    _lib.check(lib.sbg_conv2d_igemm(p, _lib.stream_ptr(x.device)), "sbg_conv2d_igemm")
+
+
 def _launch_groups(taps):
     """split a tap list into launches of at most SBG_MAX_TAPS taps"""
     m = _lib.SBG_MAX_TAPS
@@ -239,6 +266,10 @@ def _conv_transpose_forward(x, w, stride, padding, output_padding):
     if need_zero:
         y.zero_()
     first = True
+    if (not multi and 2 <= len(phases) <= 4 and sum(len(t) for *_, t in phases) <= _lib.SBG_MAX_TAPS):
+        xa, wa = passes[0]
+        _igemm_phases(xa, wa.contiguous(), y, phases, s)
+        return y
     for xa, wa in passes:
         wa = wa.contiguous()
         for a, b, goh, gow, taps in phases:
