@@ -967,7 +967,7 @@ static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStr
     // -5 % at 18+ (the 8-wave kernel's in-wave DMA issue overlaps better there)
     static const char* egl = getenv("SBG_K64_GATHER_LD");        // experiment switch: 0 never, 1 always
     const int ksteps = a.ntaps * ((a.Cin + 63) >> 6);
-    if (egl ? atoi(egl) != 0 : ksteps <= 8) return launch_gather_ld<MF>(a, xb, wb, stream);
+    if (egl ? atoi(egl) != 0 : (ksteps >= 2 && ksteps <= 8)) return launch_gather_ld<MF>(a, xb, wb, stream);      // 1 step: store-bound, the plain kernel wins
     return launch_k64<MF, 128, 256, 2, 4>(a, xb, wb, stream);
 }
 
