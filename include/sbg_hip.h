@@ -71,6 +71,8 @@ typedef struct sbg_upfirdn2d_params {
     int     inSize[4];      int64_t inStride[4];
     int     filterSize[2];  int     filterStride[2];      /* [W, H] */
     int     outSize[4];     int64_t outStride[4];
+    int     filter_exact16;  /* hint: every tap of f is exactly representable in `dtype` (bf16 / f16), so the filter may be fed to the
+                                matrix cores without rounding ([1,3,3,1]-type filters are); 0 = unknown -> fp32 vector path */
 } sbg_upfirdn2d_params;
 int sbg_upfirdn2d(const sbg_upfirdn2d_params* p, sbg_stream_t stream);
 

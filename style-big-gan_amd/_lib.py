@@ -34,6 +34,7 @@ class UpfirdnParams(ctypes.Structure):
         ("inSize", ctypes.c_int * 4), ("inStride", ctypes.c_int64 * 4),
         ("filterSize", ctypes.c_int * 2), ("filterStride", ctypes.c_int * 2),
         ("outSize", ctypes.c_int * 4), ("outStride", ctypes.c_int64 * 4),
+        ("filter_exact16", ctypes.c_int),
     ]
 
 

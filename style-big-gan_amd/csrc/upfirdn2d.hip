@@ -13,6 +13,7 @@
 //  * planar (NCHW) activations: one lane = one output pixel of one channel, lanes walk x (coalesced along rows).
 //  * the filter lives in LDS (<= 1024 taps) and is read with wave-uniform addresses (broadcast, conflict-free).
 #include "sbg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -236,15 +237,188 @@ __global__ __launch_bounds__(256) void upfirdn2d_fir_fixed_kernel(UpfirdnArgs p,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Matrix-core FIR for the hot case (up == down == 1, 4 x 4 taps, 16-bit channel-minor tensors, C % 64 == 0, taps exactly
+// representable in the tensor dtype).  The register-blocked kernels above are VALU-bound (16 fp32 FMAs + unpacking per output
+// element: 2.5 TB/s); here a row of 16 output pixels x 16 channels is ONE accumulator tile,
+//     D[c][ox] += sum_ix  In[iy = oy + ky][ix][c] * T_ky[ix][ox],      T_ky[ix][ox] = f[ky][ix - ox]  (Toeplitz, 32 x 16)
+// i.e. four v_mfma_f32_16x16x32 per tile (one per filter row), 0.4 % of the chip's matrix rate, and the VALU only converts
+// and stores.  The input window of an 8 x 32 output tile x 64 channels (11 rows x 40 pixels) is staged once by LDS-DMA in
+// whole 128-B lines; the A operand (channel x 32 consecutive pixels) is read with the transposing ds_read_b64_tr_b16.
+// Zero-padding = out-of-range DMA offsets; LDS pixels 40..47 of each row are only ever multiplied by zero taps and are
+// cleared once so that they stay finite.  `gain` is applied in fp32 on the accumulator.
+typedef __attribute__((address_space(3))) void* fir_lds_ptr;
+typedef __attribute__((address_space(3))) short4_t* fir_lds_s4_ptr;
+#define SBG_FIR_OOB 0x80000000u
+
+template <class T> struct FirMfma;
+template <> struct FirMfma<bf16_s> {
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ short bits(float v) { return (short)f32_to_bf16_bits(v); }
+};
+template <> struct FirMfma<f16_s> {
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ short bits(float v) { return (short)f32_to_f16_bits(v); }
+};
+
 template <class T>
-static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, hipStream_t stream)
+__global__ __launch_bounds__(256, 2) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs p, unsigned x_bytes, int tiles_x, int tiles_y, int cblocks)
+{
+    constexpr int TY = 8, TX = 32, FH = 4, FW = 4;
+    constexpr int WY = TY + FH - 1;                    // 11 window rows
+    constexpr int WXL = 48;                            // LDS row pitch in pixels: the K window of the second 16-pixel segment ends at 16 + 32
+    constexpr int PPR = 5;                             // DMA pieces (8 pixels) per window row: pixels 0..39 (35 needed)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int cb0 = b % cblocks; b /= cblocks;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; const int n = b / tiles_y;
+    const int ox0 = tx * TX, oy0 = ty * TY;
+
+    // clear pixels 40..47 of every window row (8 x 128 B each): 11 rows x 64 chunks of 16 B
+    for (int i = tid; i < WY * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        *reinterpret_cast<float4_t*>(fsm + ((r * WXL + 40) * 128) + c * 16) = float4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // stage the window: piece = 8 pixels x 128 B, lane -> (pixel row = lane / 8, LDS chunk = lane % 8); the 16-B chunk pairs of LDS
+    // row R are XOR-swizzled by (R >> 1) & 3 on the source side and in the transposing reads (as in conv_wgrad.hip)
+    {
+        __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
+        const int drow = lane >> 3, dchunk = lane & 7;
+        for (int piece = wave; piece < WY * PPR; piece += 4) {
+            const int r = piece / PPR, j = piece - r * PPR;
+            const int R = r * WXL + j * 8 + drow;
+            const int sc = (((dchunk >> 1) ^ ((R >> 1) & 3)) << 1) | (dchunk & 1);
+            const int iy = oy0 - p.pady0 + r, ix = ox0 - p.padx0 + j * 8 + drow;
+            const unsigned okm = 0u - (unsigned)(((unsigned)iy < (unsigned)p.inH) & ((unsigned)ix < (unsigned)p.inW));
+            const unsigned real = (unsigned)(n * (int)p.isn + iy * (int)p.isy + ix * (int)p.isx + cb0 * 64 + sc * 8) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (fir_lds_ptr)(fsm + (r * WXL + j * 8) * 128), 16, (real & okm) | (SBG_FIR_OOB & ~okm), 0, 0, 0);
+        }
+    }
+    // Toeplitz operand, constant per lane: B lane (n = output pixel = lane & 15, k-group g = lane >> 4) element j multiplies the
+    // input pixel kpix(g, j) = j < 4 ? 4g + j : 16 + 4g + (j - 4)  -- the k order of the transposing reads below
+    const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
+    short8_t bt[FH];
+#pragma unroll
+    for (int ky = 0; ky < FH; ky++) {
+        const int fy = p.flip ? ky : FH - 1 - ky;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int kpix = j < 4 ? 4 * fg + j : 16 + 4 * fg + (j - 4);
+            const int kx = kpix - fi;
+            float v = 0.f;
+            if (kx >= 0 && kx < FW) v = p.f[fy * p.fsy + (p.flip ? kx : FW - 1 - kx) * p.fsx];
+            bt[ky][j] = FirMfma<T>::bits(v);
+        }
+    }
+    // per-lane byte offsets of the transposing A reads (rows = pixels 4g + q and 16 + 4g + q of the K window, 16 channels at `col`)
+    auto frag_off = [&](int Rrel, int col) {
+        const int chunk = (col >> 3) + (fp >> 1);
+        const int sw = (((chunk >> 1) ^ ((Rrel >> 1) & 3)) << 1) | (chunk & 1);
+        return Rrel * 128 + sw * 16 + (fp & 1) * 8;
+    };
+    int offA[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) offA[c] = frag_off(4 * fg + fq, c * 16);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float4_t acc[2][2][4];                               // [output row of this wave][16-pixel segment][16-channel block]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[a][sg][c] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rl = 0; rl < 2 + FH - 1; rl++) {            // the five window rows behind this wave's two output rows
+        const unsigned char* rowp = fsm + ((2 * wave + rl) * WXL) * 128;
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const unsigned char* q = rowp + sg * 16 * 128 + offA[c];
+                const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fir_lds_s4_ptr)q);
+                const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fir_lds_s4_ptr)(q + 16 * 128));
+                const short8_t fa = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const int ky = rl - a;
+                    if (ky < 0 || ky >= FH) continue;
+                    acc[a][sg][c] = FirMfma<T>::run(fa, bt[ky], acc[a][sg][c]);
+                }
+            }
+    }
+    // D tile: lane holds channels cb*16 + 4 fg + {0..3} of output pixel seg*16 + (lane & 15).  v_permlane16_swap_b32 exchanges the
+    // odd 16-lane rows of one channel block with the even rows of the next, after which lane group fg holds EIGHT consecutive
+    // channels -- block c + (fg & 1), offset 8 (fg >> 1) -- and stores 16 B instead of 2 x 8 B (the store path is issue-bound).
+    T* yb = (T*)p.y + n * p.osn + cb0 * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const int oy = oy0 + 2 * wave + a;
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++) {
+            const int ox = ox0 + sg * 16 + fi;
+            const bool ok = oy < p.outH && ox < p.outW;
+            T* dst = yb + oy * p.osy + ox * p.osx;
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                const float4_t va = acc[a][sg][c] * p.gain, vb = acc[a][sg][c + 1] * p.gain;
+                const unsigned a0 = (unsigned)(unsigned short)FirMfma<T>::bits(va[0]) | ((unsigned)(unsigned short)FirMfma<T>::bits(va[1]) << 16);
+                const unsigned a1 = (unsigned)(unsigned short)FirMfma<T>::bits(va[2]) | ((unsigned)(unsigned short)FirMfma<T>::bits(va[3]) << 16);
+                const unsigned b0 = (unsigned)(unsigned short)FirMfma<T>::bits(vb[0]) | ((unsigned)(unsigned short)FirMfma<T>::bits(vb[1]) << 16);
+                const unsigned b1 = (unsigned)(unsigned short)FirMfma<T>::bits(vb[2]) | ((unsigned)(unsigned short)FirMfma<T>::bits(vb[3]) << 16);
+                const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);      // all lanes take part (no divergence above)
+                const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                typedef __attribute__((ext_vector_type(4))) unsigned uint4_t;
+                const uint4_t o = {r0[0], r1[0], r0[1], r1[1]};
+                if (ok) *reinterpret_cast<uint4_t*>(dst + c * 16) = o;
+            }
+        }
+    }
+}
+
+template <class T>
+static bool launch_fir_mfma(const UpfirdnArgs& a, hipStream_t stream)
+{
+    constexpr int lds = 11 * 48 * 128;
+    const int64_t x_bytes = 2 * ((int64_t)(a.N - 1) * a.isn + (int64_t)(a.inH - 1) * a.isy + (int64_t)(a.inW - 1) * a.isx + a.C);
+    if (x_bytes >= (int64_t)SBG_FIR_OOB || a.isn < 0 || a.isy < 0 || a.isx < 0) return false;
+    const int tiles_x = (a.outW + 31) / 32, tiles_y = (a.outH + 7) / 8, cblocks = a.C / 64;
+    const int64_t nblk = (int64_t)a.N * tiles_y * tiles_x * cblocks;
+    if (nblk > INT32_MAX || nblk <= 0) return false;
+    auto kern = upfirdn2d_fir_mfma_kernel<T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, tiles_y, cblocks);
+    return true;
+}
+
+template <class T> static bool try_fir_mfma(const UpfirdnArgs& a, hipStream_t stream) { return launch_fir_mfma<T>(a, stream); }
+template <> bool try_fir_mfma<float>(const UpfirdnArgs&, hipStream_t) { return false; }
+
+template <class T>
+static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, bool exact16, hipStream_t stream)
 {
     UpfirdnArgs a = a0;
     const double es = sizeof(T) == 4 ? 4 : 2;
     SbgProfScope prof(stream, SBG_K_UPFIRDN2D, 0.0,
                       es * ((double)a.N * a.C * a.inH * a.inW + (double)a.N * a.C * a.outH * a.outW),
                       {a.N, a.C, a.inH, a.inW, a.outH, a.outW, a.upx * 16 + a.downx});
-    if (vec8 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw <= FIR_MAXF && a.fh <= FIR_MAXF && a.fw * a.fh > 1) {
+    if (vec8 && exact16 && sizeof(T) == 2 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw == 4 && a.fh == 4 && (a.C % 64) == 0
+        && a.outW >= 16 && a.outH >= 8 && getenv("SBG_FIR_NO_MFMA") == nullptr && try_fir_mfma<T>(a, stream)) {
+        // matrix-core FIR
+    } else if (vec8 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw <= FIR_MAXF && a.fh <= FIR_MAXF && a.fw * a.fh > 1) {
         const int xblocks = (a.outW + FIR_TX - 1) / FIR_TX, yblocks = (a.outH + FIR_TY - 1) / FIR_TY;
         a.total = (int64_t)a.N * yblocks * xblocks * (a.C >> 3);
         if (a.fw == 4 && a.fh == 4)
@@ -297,7 +471,8 @@ extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)
                 mult8(a.isx) && mult8(a.isy) && mult8(a.isn) && mult8(a.osx) && mult8(a.osy) && mult8(a.osn) &&
                 (es == 2 || ((a.isx | a.isy | a.isn | a.osx | a.osy | a.osn) % 4) == 0);
     hipStream_t s = (hipStream_t)stream;
-    if (q->dtype == SBG_F32) return launch_upfirdn<float>(a, vec8, s);
-    if (q->dtype == SBG_F16) return launch_upfirdn<f16_s>(a, vec8, s);
-    return launch_upfirdn<bf16_s>(a, vec8, s);
+    const bool exact16 = q->filter_exact16 != 0;
+    if (q->dtype == SBG_F32) return launch_upfirdn<float>(a, vec8, false, s);
+    if (q->dtype == SBG_F16) return launch_upfirdn<f16_s>(a, vec8, exact16, s);
+    return launch_upfirdn<bf16_s>(a, vec8, exact16, s);
 }

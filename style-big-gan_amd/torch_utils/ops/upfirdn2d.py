@@ -96,8 +96,25 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     p.filterStride[:] = [f2d.stride(1), f2d.stride(0)]
     p.outSize[:] = [ow, oh, c, n]
     p.outStride[:] = [y.stride(3), y.stride(2), y.stride(1), y.stride(0)]
+    p.filter_exact16 = int(x.dtype != torch.float32 and upx == upy == downx == downy == 1 and (fh, fw) == (4, 4) and _taps_exact(f2d, x.dtype))
     _lib.check(lib.sbg_upfirdn2d(p, _lib.stream_ptr(x.device)), "sbg_upfirdn2d")
     return y
+
+
+_exact_cache = {}
+
+
+def _taps_exact(f, dtype):
+    """are all taps of f exactly representable in `dtype`?  (the matrix-core FIR path takes the filter in the tensor dtype.)  One device
+    -> host read per filter tensor and version, cached; filters are module buffers that never change during training."""
+    key = (f.data_ptr(), f._version, tuple(f.shape), tuple(f.stride()), dtype)
+    hit = _exact_cache.get(key)
+    if hit is None:
+        if len(_exact_cache) > 256:
+            _exact_cache.clear()
+        hit = bool((f.to(dtype).to(torch.float32) == f).all().item())
+        _exact_cache[key] = hit
+    return hit
 
 
 class _Upfirdn2d(torch.autograd.Function):

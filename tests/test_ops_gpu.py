@@ -138,6 +138,24 @@ def test_upfirdn2d(dev, fname, updown):
             check(g2g, g2r, TOL[dtype] * 2, f"upfirdn grad-of-grad {fname} {updown} {padding}")
 
 
+def test_upfirdn2d_matrix_core_fir(dev):
+    """4x4 low-pass, up = down = 1, bf16 / f16 channel-minor tensors with C % 64 == 0: the matrix-core FIR kernel (Toeplitz MFMA),
+    incl. every padding the layers use, crops, ragged tile edges, flip, gain and the fp32 fallback for inexact taps."""
+    torch.manual_seed(12)
+    f = O.setup_filter([1, 3, 3, 1])
+    f_asym = torch.tensor([[1., 2., 4., 8.], [0.5, 1., 2., 4.], [3., 1., 0.25, 2.], [1., 1., 1., 1.]]) / 8     # exact in bf16, not symmetric
+    f_inexact = f * 1.0001
+    for dtype in [torch.bfloat16, torch.float16]:
+        for (n, c, h, w, pad, gain, flip, ff) in [(2, 64, 33, 65, [1, 1, 1, 1], 4.0, False, f), (1, 128, 16, 32, [2, 2, 2, 2], 1.0, False, f),
+                                                  (2, 64, 40, 24, [2, 1, 2, 1], 1.0, True, f_asym), (1, 192, 9, 70, [1, 2, 0, 3], 2.0, False, f_asym),
+                                                  (1, 64, 20, 40, [-1, 2, 2, -1], 1.0, False, f), (1, 64, 17, 33, [1, 1, 1, 1], 1.0, False, f_inexact)]:
+            x = torch.randn(n, c, h, w).to(dtype).float()
+            ref = O.upfirdn2d(x, ff, padding=pad, gain=gain, flip_filter=flip)
+            xg = x.to(dev, dtype).contiguous(memory_format=torch.channels_last)
+            got = upfirdn2d.upfirdn2d(xg, ff.to(dev), padding=pad, gain=gain, flip_filter=flip)
+            check(got, ref, TOL[dtype], f"mfma fir {dtype} c{c} {h}x{w} pad{pad}")
+
+
 def test_upfirdn2d_wrappers(dev):
     torch.manual_seed(4)
     f = O.setup_filter([1, 3, 3, 1])
