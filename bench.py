@@ -64,8 +64,8 @@ def summarize_kernels(records):
 
 
 # kernel kind of the launch log -> kernel names in the rocprofv3 traces
-PMC_KERNELS = {'conv_igemm': ('conv_halo_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel'),
-               'conv_wgrad': ('conv_wgrad_rows_kernel', 'conv_wgrad_kernel'), 'upfirdn2d': ('upfirdn2d_fir_kernel', 'upfirdn2d_kernel'),
+PMC_KERNELS = {'conv_igemm': ('conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel'),
+               'conv_wgrad': ('conv_wgrad_rows_kernel', 'conv_wgrad_kernel'), 'upfirdn2d': ('upfirdn2d_fir', 'upfirdn2d_kernel'),
                'bias_act': ('bias_act',), 'scale_nc': ('scale_nc',), 'dot_hw': ('dot_hw',)}
 
 
@@ -82,9 +82,9 @@ def pmc_traffic(kind):
     except Exception:
         return None, None
     tot = n = 0
-    for name in PMC_KERNELS.get(kind, ()):
-        if name in data and data[name]['launches'] > 0:
-            tot += data[name]['hbm_bytes_per_launch'] * data[name]['launches']; n += data[name]['launches']
+    for key, rec in data.items():            # keys are kernel names, possibly truncated C++ signatures
+        if any(name in key for name in PMC_KERNELS.get(kind, ())) and rec['launches'] > 0:
+            tot += rec['hbm_bytes_per_launch'] * rec['launches']; n += rec['launches']
     return (round(tot / n), os.path.relpath(files[-1], ROOT)) if n else (None, None)
 
 

@@ -14,7 +14,7 @@ def find(sub, suffix):
 
 
 def short(name):
-    for key in ('conv_halo_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel', 'conv_wgrad_rows_kernel', 'conv_wgrad_kernel',
+    for key in ('conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_ksplit_reduce_kernel', 'upfirdn2d_fir_mfma_kernel', 'upfirdn2d_fir_fixed_kernel', 'modconv_bwd_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel', 'conv_wgrad_rows_kernel', 'conv_wgrad_kernel',
                 'wgrad_reduce_kernel', 'upfirdn2d_fir_kernel', 'upfirdn2d_kernel', 'bias_act', 'scale_nc', 'dot_hw'):
         if key in name:
             return key
