@@ -96,6 +96,32 @@ def _sum_to_bias(t, dim):
     return t.sum([i for i in range(t.ndim) if i != dim])
 
 
+_FUSED_ACTS = {"linear": 1, "relu": 2, "lrelu": 3}
+
+
+def _grad_and_bias_sum(dy, y, cfg):
+    """First-order backward of a piecewise-linear bias_act in ONE pass over (dy, y): returns (dx, db) with
+    dx = dy * gain * (y > 0 ? 1 : alpha) * [|y| < clamp] and db = dx summed over N, H, W (fp32 accumulation, fixed order).
+    Uses sbg_modconv_bwd with unit demodulation (csrc/modulate.hip); None when the layout / activation does not fit, in which
+    case the caller takes the generic differentiable path (bias_act.py:159-210 of the reference)."""
+    if (torch.is_grad_enabled() or cfg.act not in _FUSED_ACTS or cfg.dim != 1 or y.ndim != 4 or y.device.type != "cuda"
+            or y.dtype not in (torch.bfloat16, torch.float16) or not y.is_contiguous(memory_format=torch.channels_last) or y.shape[1] == 1):
+        return None
+    lib = _lib.load()
+    n, c, h, w = y.shape
+    if not lib.sbg_modconv_bwd_supported(c):
+        return None
+    dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
+    ones = torch.ones([n, c], dtype=torch.float32, device=y.device)
+    ns = lib.sbg_dot_hw_splits(1, n, c, h * w)
+    part = torch.empty([2, ns, n, c], dtype=torch.float32, device=y.device)
+    dx = torch.empty_like(y)
+    _lib.check(lib.sbg_modconv_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(ones), None, None, _lib.ptr(dx), _lib.ptr(part), None,
+                                   _lib.dtype_code(y.dtype), n, c, h * w, 0, _FUSED_ACTS[cfg.act], float(cfg.alpha), float(cfg.gain),
+                                   float(cfg.clamp), _lib.stream_ptr(y.device)), "sbg_modconv_bwd")
+    return dx, part[0].sum([0, 1])
+
+
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b, cfg):
@@ -113,6 +139,10 @@ class _BiasAct(torch.autograd.Function):
         x, b, y = ctx.saved_tensors
         cfg = ctx.cfg
         dx = db = None
+        if ctx.needs_input_grad[1] and not cfg.trivial and y is not None and b is not None:
+            fused = _grad_and_bias_sum(dy, y, cfg)          # first order, piecewise-linear activation: dx and db in one pass
+            if fused is not None:
+                return fused[0], fused[1].to(b.dtype), None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx = dy.contiguous(memory_format=ctx.fmt)
             if not cfg.trivial:

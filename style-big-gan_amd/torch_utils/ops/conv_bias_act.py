@@ -32,8 +32,13 @@ class _ConvBiasAct(torch.autograd.Function):
         bcfg = _ba._Cfg((1, act, float(alpha), float(gain), float(clamp)))
         fmt = torch.channels_last
         d1 = dy.contiguous(memory_format=fmt)
+        db_fused = None
         if not bcfg.trivial:
-            d1 = _ba._BiasActGrad.apply(d1, None, None, y, bcfg, fmt)
+            fused = _ba._grad_and_bias_sum(d1, y, bcfg) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            if fused is not None:           # first order: activation gradient and bias gradient in one pass over (dy, y)
+                d1, db_fused = fused
+            else:
+                d1 = _ba._BiasActGrad.apply(d1, None, None, y, bcfg, fmt)
         dx = dw = db = None
         ccfg = (False, stride, padding, (0, 0))
         if ctx.needs_input_grad[0]:
@@ -42,7 +47,7 @@ class _ConvBiasAct(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
             dw = _cg._ConvWgrad.apply(d1, x, ccfg, tuple(w.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _ba._sum_to_bias(d1, 1)
+            db = db_fused.to(d1.dtype) if db_fused is not None else _ba._sum_to_bias(d1, 1)
         return dx, dw, db, None
 
 
