@@ -71,9 +71,16 @@ typedef struct sbg_upfirdn2d_params {
     int     inSize[4];      int64_t inStride[4];
     int     filterSize[2];  int     filterStride[2];      /* [W, H] */
     int     outSize[4];     int64_t outStride[4];
+    /* Optional fused tail (the `fma(x, dcoefs, noise)` + `bias_act` that follow the low-pass of an up-sampling synthesis layer,
+     * train_parts/generators.py:84-88,328):  y = clamp(act(fir * gain * oscale[n*C + c] + noise[n*noise_stride_n + oy*outW + ox] + bias[c]) * act_gain).
+     * fp32 arrays, each may be NULL; act in {0 = no tail, linear, relu, lrelu}; clamp < 0 disables.  Only the matrix-core FIR path
+     * (16-bit channel-minor tensors, up = down = 1, 4x4 exact taps, C % 64 == 0) applies it: sbg_upfirdn2d_tail_supported(). */
+    const float* oscale; const float* noise; int64_t noise_stride_n; const float* bias;
+    int act; float alpha, act_gain, clamp;
     int     filter_exact16;  /* hint: every tap of f is exactly representable in `dtype` (bf16 / f16), so the filter may be fed to the
                                 matrix cores without rounding ([1,3,3,1]-type filters are); 0 = unknown -> fp32 vector path */
 } sbg_upfirdn2d_params;
+int sbg_upfirdn2d_tail_supported(const sbg_upfirdn2d_params* p);
 int sbg_upfirdn2d(const sbg_upfirdn2d_params* p, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

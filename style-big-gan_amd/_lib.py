@@ -34,6 +34,8 @@ class UpfirdnParams(ctypes.Structure):
         ("inSize", ctypes.c_int * 4), ("inStride", ctypes.c_int64 * 4),
         ("filterSize", ctypes.c_int * 2), ("filterStride", ctypes.c_int * 2),
         ("outSize", ctypes.c_int * 4), ("outStride", ctypes.c_int64 * 4),
+        ("oscale", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("noise_stride_n", ctypes.c_int64), ("bias", ctypes.c_void_p),
+        ("act", ctypes.c_int), ("alpha", ctypes.c_float), ("act_gain", ctypes.c_float), ("clamp", ctypes.c_float),
         ("filter_exact16", ctypes.c_int),
     ]
 
@@ -88,7 +90,8 @@ SYMBOLS = [
     ("sbg_last_error", _c.c_char_p, []),
     ("sbg_bias_act", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
                                                    _c.c_int64, _c.c_int, _c.c_int64, _c.c_void_p]),
-    ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
+("sbg_upfirdn2d_tail_supported", _c.c_int, [_c.POINTER(UpfirdnParams)]),
+        ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
     ("sbg_conv2d_igemm_workspace", _c.c_int64, [_c.POINTER(ConvParams)]),
     ("sbg_conv2d_igemm", _c.c_int, [_c.POINTER(ConvParams), _c.c_void_p]),
     ("sbg_conv2d_wgrad_workspace", _c.c_int64, [_c.POINTER(WgradParams)]),

@@ -24,6 +24,9 @@ struct UpfirdnArgs {
     int fw, fh, fsx, fsy;
     int outW, outH; int64_t osx, osy, osc, osn;
     int64_t total;    // number of lane work items
+    // fused tail (matrix-core FIR only): y = clamp(act(fir * gain * oscale[n, c] + noise[n, pixel] + bias[c]) * act_gain)
+    const float* oscale; const float* noise; int64_t noise_sn; const float* bias;
+    int tail; float alpha, act_gain, clamp;
 };
 
 #define SBG_UPFIRDN_MAX_LDS_TAPS 1024
@@ -360,6 +363,17 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs 
     // odd 16-lane rows of one channel block with the even rows of the next, after which lane group fg holds EIGHT consecutive
     // channels -- block c + (fg & 1), offset 8 (fg >> 1) -- and stores 16 B instead of 2 x 8 B (the store path is issue-bound).
     T* yb = (T*)p.y + n * p.osn + cb0 * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
+    // fused tail, applied in fp32 before the exchange: this lane's channels are cb0*64 + 16 c + 4 fg + {0..3}
+    float4_t t_scale[4], t_bias[4];
+    const float t_alpha = p.tail ? p.alpha : 1.f, t_gain = p.tail ? p.act_gain : 1.f, t_cl = (p.tail && p.clamp >= 0.f) ? p.clamp : __builtin_inff();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int ch = cb0 * 64 + c * 16 + 4 * fg;
+        t_scale[c] = float4_t{p.gain, p.gain, p.gain, p.gain};
+        t_bias[c] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.tail && p.oscale) t_scale[c] *= *reinterpret_cast<const float4_t*>(p.oscale + (int64_t)n * p.C + ch);
+        if (p.tail && p.bias)   t_bias[c] = *reinterpret_cast<const float4_t*>(p.bias + ch);
+    }
 #pragma unroll
     for (int a = 0; a < 2; a++) {
         const int oy = oy0 + 2 * wave + a;
@@ -368,9 +382,17 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs 
             const int ox = ox0 + sg * 16 + fi;
             const bool ok = oy < p.outH && ox < p.outW;
             T* dst = yb + oy * p.osy + ox * p.osx;
+            const float nz = (p.tail && p.noise && ok) ? p.noise[n * p.noise_sn + (int64_t)oy * p.outW + ox] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float4_t v = acc[a][sg][c] * t_scale[c] + (t_bias[c] + nz);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { float u = v[e]; u = (u > 0.f) ? u : u * t_alpha; v[e] = __builtin_amdgcn_fmed3f(u * t_gain, -t_cl, t_cl); }
+                acc[a][sg][c] = v;
+            }
 #pragma unroll
             for (int c = 0; c < 4; c += 2) {
-                const float4_t va = acc[a][sg][c] * p.gain, vb = acc[a][sg][c + 1] * p.gain;
+                const float4_t va = acc[a][sg][c], vb = acc[a][sg][c + 1];
                 const unsigned a0 = (unsigned)(unsigned short)FirMfma<T>::bits(va[0]) | ((unsigned)(unsigned short)FirMfma<T>::bits(va[1]) << 16);
                 const unsigned a1 = (unsigned)(unsigned short)FirMfma<T>::bits(va[2]) | ((unsigned)(unsigned short)FirMfma<T>::bits(va[3]) << 16);
                 const unsigned b0 = (unsigned)(unsigned short)FirMfma<T>::bits(vb[0]) | ((unsigned)(unsigned short)FirMfma<T>::bits(vb[1]) << 16);
@@ -418,6 +440,8 @@ static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, bool exact16, hipStr
     if (vec8 && exact16 && sizeof(T) == 2 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw == 4 && a.fh == 4 && (a.C % 64) == 0
         && a.outW >= 16 && a.outH >= 8 && getenv("SBG_FIR_NO_MFMA") == nullptr && try_fir_mfma<T>(a, stream)) {
         // matrix-core FIR
+    } else if (a.tail) {
+        return sbg_fail(SBG_ERR_UNSUPPORTED, "upfirdn2d: fused tail requested but the matrix-core FIR path does not take this launch");
     } else if (vec8 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw <= FIR_MAXF && a.fh <= FIR_MAXF && a.fw * a.fh > 1) {
         const int xblocks = (a.outW + FIR_TX - 1) / FIR_TX, yblocks = (a.outH + FIR_TY - 1) / FIR_TY;
         a.total = (int64_t)a.N * yblocks * xblocks * (a.C >> 3);
@@ -437,6 +461,15 @@ static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, bool exact16, hipStr
 }
 
 } // namespace
+
+extern "C" int sbg_upfirdn2d_tail_supported(const sbg_upfirdn2d_params* q)
+{
+    if (!q) return 0;
+    const int C = q->inSize[2];
+    return (q->dtype == SBG_BF16 || q->dtype == SBG_F16) && q->filter_exact16 && q->upx == 1 && q->upy == 1 && q->downx == 1 && q->downy == 1
+           && q->filterSize[0] == 4 && q->filterSize[1] == 4 && (C % 64) == 0 && q->outSize[0] >= 16 && q->outSize[1] >= 8
+           && q->inStride[2] == 1 && q->outStride[2] == 1 && getenv("SBG_FIR_NO_MFMA") == nullptr;
+}
 
 extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)
 {
@@ -463,6 +496,9 @@ extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)
     a.outW = q->outSize[0]; a.outH = q->outSize[1];
     a.osx = q->outStride[0]; a.osy = q->outStride[1]; a.osc = q->outStride[2]; a.osn = q->outStride[3];
     a.total = 0;
+    a.oscale = q->oscale; a.noise = q->noise; a.noise_sn = q->noise_stride_n; a.bias = q->bias;
+    a.tail = (q->act != 0) ? 1 : 0;
+    a.alpha = q->act == SBG_ACT_LRELU ? q->alpha : (q->act == SBG_ACT_RELU ? 0.f : 1.f); a.act_gain = q->act_gain; a.clamp = q->clamp;
 
     // 8-channel vector path: channel-minor on both sides, every pixel start 16-B aligned.
     const int es = sbg_dtype_size(q->dtype);
@@ -472,6 +508,11 @@ extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)
                 (es == 2 || ((a.isx | a.isy | a.isn | a.osx | a.osy | a.osn) % 4) == 0);
     hipStream_t s = (hipStream_t)stream;
     const bool exact16 = q->filter_exact16 != 0;
+    if (a.tail) {
+        SBG_CHECK(q->act == SBG_ACT_LINEAR || q->act == SBG_ACT_RELU || q->act == SBG_ACT_LRELU, "upfirdn2d: fused activation must be linear, relu or lrelu");
+        SBG_CHECK(vec8 && sbg_upfirdn2d_tail_supported(q), "upfirdn2d: the fused tail needs the matrix-core FIR path (sbg_upfirdn2d_tail_supported)");
+        SBG_CHECK((!q->oscale || sbg_aligned16(q->oscale)) && (!q->bias || sbg_aligned16(q->bias)), "upfirdn2d: oscale / bias must be 16-byte aligned");
+    }
     if (q->dtype == SBG_F32) return launch_upfirdn<float>(a, vec8, false, s);
     if (q->dtype == SBG_F16) return launch_upfirdn<f16_s>(a, vec8, exact16, s);
     return launch_upfirdn<bf16_s>(a, vec8, exact16, s);

@@ -69,8 +69,10 @@ def setup_filter(f, device=torch.device("cpu"), normalize=True, flip_filter=Fals
     return f.to(device=device)
 
 
-def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
-    """One sbg_upfirdn2d launch on a rank-2 filter; output keeps x's memory format (reference: upfirdn2d.cpp:35)."""
+def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, tail=None, probe=False):
+    """One sbg_upfirdn2d launch on a rank-2 filter; output keeps x's memory format (reference: upfirdn2d.cpp:35).
+    `tail` = dict(oscale, noise, bias, act, alpha, gain, clamp): fused demodulation / noise / bias_act epilogue (matrix-core FIR path only);
+    `probe=True` returns whether that path would take this launch with a tail, without launching."""
     lib = _lib.load()
     if x.ndim != 4:
         raise RuntimeError("upfirdn2d: x must be rank 4")
@@ -97,6 +99,25 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     p.outSize[:] = [ow, oh, c, n]
     p.outStride[:] = [y.stride(3), y.stride(2), y.stride(1), y.stride(0)]
     p.filter_exact16 = int(x.dtype != torch.float32 and upx == upy == downx == downy == 1 and (fh, fw) == (4, 4) and _taps_exact(f2d, x.dtype))
+    if probe:
+        return bool(cl and lib.sbg_upfirdn2d_tail_supported(p))
+    keep = []
+    if tail is not None:
+        def f32(t, shape):
+            t = t.detach().to(torch.float32).reshape(shape).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+        if tail.get("oscale") is not None:
+            p.oscale = f32(tail["oscale"], [n, c])
+        if tail.get("bias") is not None:
+            p.bias = f32(tail["bias"], [c])
+        if tail.get("noise") is not None:
+            nz = tail["noise"]
+            per_sample = nz.numel() != oh * ow
+            p.noise = f32(nz, [n if per_sample else 1, oh * ow])
+            p.noise_stride_n = oh * ow if per_sample else 0
+        p.act = {"linear": 1, "relu": 2, "lrelu": 3}[tail["act"]]
+        p.alpha, p.act_gain, p.clamp = float(tail["alpha"]), float(tail["gain"]), float(tail["clamp"])
     _lib.check(lib.sbg_upfirdn2d(p, _lib.stream_ptr(x.device)), "sbg_upfirdn2d")
     return y
 
@@ -151,6 +172,76 @@ class _Upfirdn2d(torch.autograd.Function):
                     not flip, gain)
             dx = _Upfirdn2d.apply(dy, f, gcfg)
         return dx, None, None
+
+
+class _FirBiasAct(torch.autograd.Function):
+    """y = clamp(act(upfirdn2d(t, f, padding, gain) * dcoefs[n, c] + noise + b) * act_gain) in one kernel (up = down = 1; the low-pass after
+    the transposed convolution of an up-sampling synthesis layer with the layer's whole tail, generators.py:84-88,328).  Backward: one pass
+    over (dy, y) (sbg_modconv_bwd) gives the gradient w.r.t. the filtered tensor and the bias / demodulation / noise gradients, then the
+    transposed FIR.  First order only (see ops/modconv.py).   cfg = (padx0, padx1, pady0, pady1, flip, gain, act, alpha, act_gain, clamp)"""
+
+    @staticmethod
+    def forward(ctx, t, f, dcoefs, noise, b, cfg):
+        padx0, padx1, pady0, pady1, flip, gain, act, alpha, act_gain, clamp = cfg
+        y = _launch(t, f, 1, 1, 1, 1, padx0, padx1, pady0, pady1, flip, gain,
+                    tail=dict(oscale=dcoefs, noise=noise, bias=b, act=act, alpha=alpha, gain=act_gain, clamp=clamp))
+        ctx.save_for_backward(f, dcoefs, noise, b, y)
+        ctx.cfg, ctx.in_hw = cfg, (t.shape[2], t.shape[3])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, dcoefs, noise, b, y = ctx.saved_tensors
+        padx0, padx1, pady0, pady1, flip, gain, act, alpha, act_gain, clamp = ctx.cfg
+        if torch.is_grad_enabled():
+            raise RuntimeError("fir_bias_act: first-order only; set torch_utils.ops.modconv.enabled = False for double backward")
+        lib = _lib.load()
+        n, c, oh, ow = y.shape
+        dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
+        dc32 = (dcoefs.detach().to(torch.float32).reshape(n, c) if dcoefs is not None else torch.ones([n, c], dtype=torch.float32, device=y.device)).contiguous()
+        nz = nsn = None
+        if noise is not None:
+            nz = noise.detach().to(torch.float32)
+            per_sample = nz.numel() != oh * ow
+            nz = nz.reshape(n if per_sample else 1, oh * ow).contiguous()
+            nsn = oh * ow if per_sample else 0
+        b32 = b.detach().to(torch.float32).contiguous() if b is not None else None
+        ns = lib.sbg_dot_hw_splits(1, n, c, oh * ow)
+        part = torch.empty([2, ns, n, c], dtype=torch.float32, device=y.device)
+        d2 = torch.empty_like(y)
+        want_dn = noise is not None and ctx.needs_input_grad[3]
+        dn = torch.empty([n, 1, oh, ow], dtype=torch.float32, device=y.device) if want_dn else None
+        _lib.check(lib.sbg_modconv_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dc32), _lib.ptr(nz), _lib.ptr(b32), _lib.ptr(d2), _lib.ptr(part),
+                                       _lib.ptr(dn), _lib.dtype_code(y.dtype), n, c, oh * ow, nsn or 0, {"linear": 1, "relu": 2, "lrelu": 3}[act],
+                                       float(alpha), float(act_gain), float(clamp), _lib.stream_ptr(y.device)), "sbg_modconv_bwd")
+        sums = part.sum(1)
+        dt = ddc = dnoise = db = None
+        if dcoefs is not None and ctx.needs_input_grad[2]:
+            ddc = (sums[1] / dc32).to(dcoefs.dtype).reshape(dcoefs.shape)
+        if b is not None and ctx.needs_input_grad[4]:
+            db = sums[0].sum(0).to(b.dtype)
+        if want_dn:
+            dnoise = (dn if noise.numel() != oh * ow else dn.sum(0, keepdim=True)).reshape(noise.shape).to(noise.dtype)
+        if ctx.needs_input_grad[0]:
+            ih, iw = ctx.in_hw
+            fw, fh = _get_filter_size(f)
+            gcfg = (1, 1, 1, 1, fw - padx0 - 1, iw - ow + padx0, fh - pady0 - 1, ih - oh + pady0, not flip, gain)
+            dt = _Upfirdn2d.apply(d2, f, gcfg)
+        return dt, None, ddc, dnoise, db, None
+
+
+def fir_tail_supported(x, f, padding, flip_filter=False):
+    """can upfirdn2d(x, f, padding) with a fused tail run on the matrix-core FIR path?"""
+    if f is None or f.ndim != 2 or x.device.type != "cuda" or x.ndim != 4:
+        return False
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    return _launch(x, f, 1, 1, 1, 1, padx0, padx1, pady0, pady1, flip_filter, 1.0, probe=True)
+
+
+def fir_bias_act(x, f, padding, gain, dcoefs, noise, b, act="lrelu", alpha=0.2, act_gain=1.0, clamp=-1.0, flip_filter=False):
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    cfg = (padx0, padx1, pady0, pady1, bool(flip_filter), float(gain), act, float(alpha), float(act_gain), float(clamp))
+    return _FirBiasAct.apply(x, f, dcoefs, noise, b, cfg)
 
 
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="cuda"):

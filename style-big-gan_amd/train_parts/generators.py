@@ -275,6 +275,15 @@ class SynthesisLayer(torch.nn.Module):
             # training pass, first order: same fused epilogue, plus a one-pass backward head (torch_utils/ops/modconv.py)
             return modconv.modconv_bias_act(x, self.weight.to(x.dtype), styles, demod_coefficients(self.weight, styles), noise, self.bias,
                                             padding=self.padding, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        if (self.up == 2 and modconv.enabled and x.device.type == 'cuda' and x.dtype == torch.bfloat16
+                and self.activation in ('linear', 'relu', 'lrelu')):
+            # up-sampling layer, first-order training pass: x * s -> transposed convolution (one multi-phase launch) -> low-pass whose kernel
+            # epilogue carries demodulation, noise, bias, activation, gain and clamp (falls back to the composition inside conv2d_resample)
+            spec = bias_act.activation_funcs[self.activation]
+            tail = dict(dcoefs=demod_coefficients(self.weight, styles), noise=noise, b=self.bias, act=self.activation, alpha=spec.def_alpha,
+                        gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1))
+            return conv2d_resample.conv2d_resample(x=modulate.scale_nc(x, styles), w=self.weight.to(x.dtype), f=self.resample_filter, up=2,
+                                                   padding=self.padding, flip_weight=False, fir_tail=tail)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)

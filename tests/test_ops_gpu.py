@@ -370,3 +370,51 @@ def test_fused_modconv_training_layer(dev):
         for name, f_, u_, r_ in zip(["y", "dx", "dw", "dstyles", "db", "dnoise"], res["fused"], res["unfused"], res["ref"]):
             ef, eu = err(f_, r_), err(u_, r_)
             assert ef <= 1.5 * eu + 5e-3, f"modconv {name} ({act}, {noise_kind}, clamp {clamp}): fused {ef:.3e} vs composition {eu:.3e}"
+
+
+def test_fused_up_synthesis_layer(dev):
+    """Up-sampling SynthesisLayer (x * s -> multi-phase transposed conv -> low-pass with the fused tail, ops/upfirdn2d.py::_FirBiasAct)
+    vs the unfused bf16 composition, both held to an fp64 evaluation of the oracle's layer (oracle/ops.py::modulated_conv2d + bias_act):
+    the fused path must be at least as close (x1.5 + 5e-3) for y and every first-order gradient."""
+    from style_big_gan_amd.torch_utils.ops import modconv
+    from style_big_gan_amd.train_parts import generators as GN
+    torch.manual_seed(13)
+    f = O.setup_filter([1, 3, 3, 1])
+
+    def err(a, b):
+        return float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().cpu().abs().max() + 1e-12))
+
+    for (n, cin, cout, r, noise_kind, clamp) in [(2, 32, 64, 16, "per_sample", 2.0), (3, 16, 128, 8, "const", None)]:
+        layer = GN.SynthesisLayer(cin, cout, w_dim=24, resolution=2 * r, up=2, use_noise=True, conv_clamp=clamp, channels_last=True).to(dev)
+        with torch.no_grad():
+            layer.noise_strength.fill_(0.3); layer.bias.normal_()
+        x0 = torch.randn(n, cin, r, r, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w0 = torch.randn(n, 24, device=dev)
+        dy0 = torch.randn(n, cout, 2 * r, 2 * r, device=dev).to(torch.bfloat16)
+        noise_mode = "const" if noise_kind == "const" else "random"
+        res = {}
+        for mode in ("fused", "unfused"):
+            modconv.enabled = (mode == "fused")
+            try:
+                x = x0.clone().requires_grad_(True); w = w0.clone().requires_grad_(True)
+                torch.manual_seed(99)                              # same random noise in both runs
+                y = layer(x, w, noise_mode=noise_mode)
+                assert ("FirBiasAct" in type(y.grad_fn).__name__) == (mode == "fused"), type(y.grad_fn).__name__
+                params = [layer.weight, layer.bias, layer.noise_strength, layer.affine.weight]
+                g = torch.autograd.grad((y.double() * dy0.double()).sum(), [x, w] + params)
+            finally:
+                modconv.enabled = True
+            res[mode] = [y.detach()] + [t.detach() for t in g]
+        # fp64 reference of the same layer on the CPU oracle ops
+        torch.manual_seed(99)
+        noise = (torch.randn([n, 1, 2 * r, 2 * r], device=dev) if noise_mode == "random" else layer.noise_const.detach()).double().cpu()
+        xr = x0.double().cpu().requires_grad_(True); wr = w0.double().cpu().requires_grad_(True)
+        pw = [p.detach().double().cpu().requires_grad_(True) for p in (layer.weight, layer.bias, layer.noise_strength, layer.affine.weight)]
+        styles = torch.addmm(layer.affine.bias.detach().double().cpu().unsqueeze(0), wr, (pw[3] * layer.affine.weight_gain).t())
+        yr = O.modulated_conv2d(xr, pw[0], styles, noise=noise * pw[2], up=2, padding=1, resample_filter=f, flip_weight=False, fused_modconv=False)
+        yr = O.bias_act(yr, pw[1], act="lrelu", gain=layer.act_gain, clamp=clamp)
+        gr = torch.autograd.grad((yr * dy0.double().cpu()).sum(), [xr, wr] + pw)
+        ref = [yr.detach()] + [t.detach() for t in gr]
+        for name, f_, u_, r_ in zip(["y", "dx", "dw_latent", "dweight", "dbias", "dnoise_strength", "daffine"], res["fused"], res["unfused"], ref):
+            ef, eu = err(f_, r_), err(u_, r_)
+            assert ef <= 1.5 * eu + 5e-3, f"up layer {name} ({noise_kind}, clamp {clamp}): fused {ef:.3e} vs composition {eu:.3e}"
