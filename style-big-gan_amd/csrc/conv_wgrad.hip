@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 #define SBG_OOB_OFFSET 0x80000000u
 
-template <class MF, int S, int BCA>
+template <class MF, int S, int BCA, int NSTAGE>
 __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsigned a_bytes, unsigned b_bytes)
 {
     // 8 waves = 2 (ca) x 4 (cb), wave tile (BCA / 2) x 16 channels for all nine taps: two waves per SIMD overlap one wave's
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
     // b patch of a 32-pixel chunk is 65 columns wide.
     // S = stride between the coarse (a) and fine (b) grids: b pixel = S * a pixel + tap, taps = (dy0 + i, dx0 + j), i, j in 0..2
     static_assert(BCA == 64 || BCA == 128, "a tile of 64 or 128 channels");
-    constexpr int BCB = 64, NT = 9, NSTAGE = 3, DEPTH = 2;
+    constexpr int BCB = 64, NT = 9, DEPTH = NSTAGE - 1;     // NSTAGE = 2 (one chunk of loads in flight) lets two workgroups share a CU where three stages would not fit twice
     constexpr int TA = BCA / 32;                               // 16-channel a fragments per wave
     constexpr int APIECES = BCA / 16;                          // a-tile = BCA / 64 sub-tiles of [32 pixels][64 channels], 4 pieces each
     constexpr int PCOLS = S * 31 + 3;                          // b columns needed by a 32-pixel chunk
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
 #pragma unroll
     for (int s = 0; s < DEPTH; s++) if (s < nloc) issue(s);
     for (int s = 0; s < nloc; s++) {
-        if (nloc - 1 - s >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
-        else                   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DEPTH >= 2 && nloc - 1 - s >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        else                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (s + DEPTH < nloc) issue(s + DEPTH);
         const unsigned char* sA = smem + (s % NSTAGE) * STAGE;
@@ -481,28 +481,35 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
         const int s_ = q->stride;
         // stage = (a pieces + 3 x patch pieces, rounded up to 8) KiB
         auto stage_kib = [](int S, int BCA) { const int ppr = (S * 31 + 3 + 7) / 8; return ((BCA / 16 + 3 * ppr + 7) / 8) * 8; };
-        const int lds = 3 * stage_kib(s_, bca) * 1024;
+        // stride 2 with the 128-channel a tile: 40 KB stages -- two of them (80 KB) admit two workgroups per CU, three do not
+        static const char* ens = getenv("SBG_WGRAD_NSTAGE");
+        const int nst = (s_ == 2 && bca == 128 && !(ens && atoi(ens) == 3)) ? 2 : 3;
+        const int lds = nst * stage_kib(s_, bca) * 1024;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(2, 64) * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(2, 64) * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(2, 128) * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(2, 128) * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(1, 128) * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(1, 128) * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(1, 64) * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * stage_kib(1, 64) * 1024);
+            const int big = 3 * stage_kib(2, 128) * 1024;
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
             attr_set = true;
         }
         SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                           2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
                           {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, bca * 1000 + 64});
         const dim3 grid(a.atiles, a.btiles, a.nsplit);
-#define SBG_ROWS_LAUNCH(MFT, SS, BB) hipLaunchKernelGGL((conv_wgrad_rows_kernel<MFT, SS, BB>), grid, dim3(512), lds, s, a, ab, bb)
-        if (s_ == 1 && bca == 64)       { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 64);  else SBG_ROWS_LAUNCH(f16_mfma, 1, 64); }
-        else if (s_ == 1)               { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 128); else SBG_ROWS_LAUNCH(f16_mfma, 1, 128); }
-        else if (bca == 64)             { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 64);  else SBG_ROWS_LAUNCH(f16_mfma, 2, 64); }
-        else                            { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 128); else SBG_ROWS_LAUNCH(f16_mfma, 2, 128); }
+#define SBG_ROWS_LAUNCH(MFT, SS, BB, NS) hipLaunchKernelGGL((conv_wgrad_rows_kernel<MFT, SS, BB, NS>), grid, dim3(512), lds, s, a, ab, bb)
+        if (s_ == 1 && bca == 64)       { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 64, 3);  else SBG_ROWS_LAUNCH(f16_mfma, 1, 64, 3); }
+        else if (s_ == 1)               { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 128, 3); else SBG_ROWS_LAUNCH(f16_mfma, 1, 128, 3); }
+        else if (bca == 64)             { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 64, 3);  else SBG_ROWS_LAUNCH(f16_mfma, 2, 64, 3); }
+        else if (nst == 2)              { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 128, 2); else SBG_ROWS_LAUNCH(f16_mfma, 2, 128, 2); }
+        else                            { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 128, 3); else SBG_ROWS_LAUNCH(f16_mfma, 2, 128, 3); }
 #undef SBG_ROWS_LAUNCH
         SBG_HIP_LAUNCH_CHECK();
     } else if (use_big_tile(a.ntaps)) {
