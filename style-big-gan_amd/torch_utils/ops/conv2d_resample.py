@@ -30,7 +30,10 @@ def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True
 def _tail(y, tail):
     if tail is None:
         return y
-    return bias_act.bias_act(y, tail["b"], act=tail["act"], alpha=tail["alpha"], gain=tail["gain"], clamp=tail["clamp"])
+    b = tail["b"]
+    if b is not None and b.dtype != y.dtype:        # layers hand over their fp32 bias parameter (the fused conv epilogue reads fp32)
+        b = b.to(y.dtype)
+    return bias_act.bias_act(y, b, act=tail["act"], alpha=tail["alpha"], gain=tail["gain"], clamp=tail["clamp"])
 
 
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, bias_act_tail=None, fir_tail=None):

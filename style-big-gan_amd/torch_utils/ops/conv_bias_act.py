@@ -23,6 +23,7 @@ class _ConvBiasAct(torch.autograd.Function):
         ctx.save_for_backward(x, w, y)
         ctx.cfg = cfg
         ctx.has_bias = b is not None
+        ctx.b_dtype = b.dtype if b is not None else None       # fp32 parameters may be passed as they are: the epilogue reads fp32
         return y
 
     @staticmethod
@@ -47,7 +48,7 @@ class _ConvBiasAct(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
             dw = _cg._ConvWgrad.apply(d1, x, ccfg, tuple(w.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = db_fused.to(d1.dtype) if db_fused is not None else _ba._sum_to_bias(d1, 1)
+            db = (db_fused if db_fused is not None else _ba._sum_to_bias(d1, 1)).to(ctx.b_dtype)
         return dx, dw, db, None
 
 

@@ -154,7 +154,7 @@ class Conv2dLayer(torch.nn.Module):
 
     def forward(self, x, gain=1):
         w = self.weight * self.weight_gain
-        b = self.bias.to(x.dtype) if self.bias is not None else None
+        b = self.bias               # fp32 as stored: the fused epilogue takes fp32, the unfused tail casts
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         # conv2d_resample + bias_act (reference :179-184); the bias_act rides in the convolution kernel's epilogue when it can
         tail = dict(b=b, act=self.activation, alpha=None, gain=self.act_gain * gain, clamp=clamp)
@@ -304,7 +304,7 @@ class ToRGBLayer(torch.nn.Module):
         wt = self.weight.to(x.dtype)
         if conv_bias_act.fusable(x, wt, 'linear'):      # modulation pass, then 1x1 convolution with bias + clamp in its epilogue
             xs = modulate.scale_nc(x, styles)
-            return conv_bias_act.conv2d_bias_act(xs, wt, self.bias.to(x.dtype), act='linear', clamp=self.conv_clamp)
+            return conv_bias_act.conv2d_bias_act(xs, wt, self.bias, act='linear', clamp=self.conv_clamp)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 
