@@ -144,7 +144,8 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('SBG_DIST_BACKEND', 'nccl')        # 'gloo' only to rehearse N > 1 on a one-GPU box
+        torch.distributed.init_process_group(backend, **(dict(device_id=device) if backend == 'nccl' else {}))
     assert world == args.gpus or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
 
     import style_big_gan_amd
