@@ -213,6 +213,36 @@ int sbg_attention_fwd(const float* theta, const float* phi, const float* g, floa
                       sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ADA augmentation pipe, device ops (train_parts/augmentations.py:121-433).
+ *
+ * grid_sample: bilinear, zero padding, align_corners = False -- the one mode of the reference's
+ * `grid_sample_gradfix.grid_sample(input, grid)` (stylegan2ada/torch_utils/ops/grid_sample_gradfix.py:24-27,45), whose
+ * backward is `aten::grid_sampler_2d_backward(grad_output, input, grid, 0, 0, False)` (:63-64).
+ * fp32 planar tensors with element strides.  Sampling positions come from `grid` (fp32 [N, OH, OW, 2] dense, normalised
+ * coordinates) or, when `grid` is NULL, from `theta` (fp32 [N, 2, 3]): the positions `F.affine_grid(theta, [N, C, OH, OW],
+ * align_corners=False)` would produce (augmentations.py:299) are generated inside the kernel.
+ *   sbg_grid_sample2d:      y[n, c, oy, ox]  = sum over the 4 neighbours of x weighted bilinearly (x, y required)
+ *   sbg_grid_sample2d_bwd:  dx += scatter of dy (dx must be zeroed by the caller; fp32 atomics); if dgrid != NULL also
+ *                           dgrid[n, oy, ox, 2] (needs x).  dy shares y's strides, dx shares x's. */
+typedef struct sbg_grid_sample_params {
+    const void* x; const float* grid; const float* theta; const void* dy;
+    void* y; void* dx; float* dgrid;
+    int N, C, IH, IW, OH, OW;
+    int64_t xs_n, xs_c, xs_h, xs_w;
+    int64_t ys_n, ys_c, ys_h, ys_w;
+} sbg_grid_sample_params;
+int sbg_grid_sample2d(const sbg_grid_sample_params* p, sbg_stream_t stream);
+int sbg_grid_sample2d_bwd(const sbg_grid_sample_params* p, sbg_stream_t stream);
+
+/* Per-sample 1-D correlation of M dense fp32 planes [M, H, W] along W (axis 0) or H (axis 1):
+ *   y[m, .., o] = sum_t x[m, .., o + t - pad] * taps[m / planes_per_filter][flip ? T-1-t : t]      (zeros outside)
+ * = one of the two grouped convolutions of the image-space filter, `conv2d(images, Hz_prime.unsqueeze(2 or 3),
+ * groups=batch*channels)` (augmentations.py:388-389); with flip = 1 and pad = T - 1 - pad_fwd it is their data gradient.
+ * Output extent along the axis: L + 2*pad - T + 1. */
+int sbg_filter1d_batch(const float* x, const float* taps, float* y, int M, int H, int W, int T, int axis, int pad,
+                       int planes_per_filter, int flip, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * In-process launch timing (measurement only; bench.py's roofline figures come from here).
  * While enabled, every kernel launch of this library is bracketed by two hipEvents recorded on the launch stream
  * and logged with its algorithmic flops / bytes.  sbg_prof_fetch() synchronises the logged events, writes up to `max`
@@ -220,7 +250,7 @@ int sbg_attention_fwd(const float* theta, const float* phi, const float* g, floa
  * (or the number pending when out == NULL). */
 enum sbg_kernel_kind {
     SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
-    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12
 };
 typedef struct sbg_prof_record {
     int    kind;            /* enum sbg_kernel_kind */

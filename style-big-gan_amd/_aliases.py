@@ -9,6 +9,9 @@ _MAP = {
     "stylegan2ada.torch_utils.ops.conv2d_resample": "torch_utils.ops.conv2d_resample",
     "stylegan2ada.torch_utils.ops.conv2d_gradfix": "torch_utils.ops.conv2d_gradfix",
     "stylegan2ada.torch_utils.ops.fma": "torch_utils.ops.fma",
+    "stylegan2ada.torch_utils.ops.grid_sample_gradfix": "torch_utils.ops.grid_sample_gradfix",
+    "stylegan2ada.training.augment": "train_parts.augmentations",
+    "train_parts.augmentations": "train_parts.augmentations",
     "stylegan2ada.torch_utils.misc": "torch_utils.misc",
     "stylegan2ada.torch_utils.training_stats": "torch_utils.training_stats",
     "train_parts.generators": "train_parts.generators",

@@ -73,12 +73,23 @@ class WgradParams(ctypes.Structure):
     ]
 
 
+class GridSampleParams(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("grid", ctypes.c_void_p), ("theta", ctypes.c_void_p), ("dy", ctypes.c_void_p),
+        ("y", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("dgrid", ctypes.c_void_p),
+        ("N", ctypes.c_int), ("C", ctypes.c_int), ("IH", ctypes.c_int), ("IW", ctypes.c_int), ("OH", ctypes.c_int), ("OW", ctypes.c_int),
+        ("xs_n", ctypes.c_int64), ("xs_c", ctypes.c_int64), ("xs_h", ctypes.c_int64), ("xs_w", ctypes.c_int64),
+        ("ys_n", ctypes.c_int64), ("ys_c", ctypes.c_int64), ("ys_h", ctypes.c_int64), ("ys_w", ctypes.c_int64),
+    ]
+
+
 class ProfRecord(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("dims", ctypes.c_int * 7), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
                 ("ms", ctypes.c_float), ("pad", ctypes.c_int)]
 
 
-KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 9: "sn_power", 10: "attention"}
+KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 9: "sn_power", 10: "attention",
+                11: "grid_sample", 12: "filter1d"}
 
 _lib = None
 _lock = threading.Lock()
@@ -90,8 +101,8 @@ SYMBOLS = [
     ("sbg_last_error", _c.c_char_p, []),
     ("sbg_bias_act", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _c.c_float,
                                                    _c.c_int64, _c.c_int, _c.c_int64, _c.c_void_p]),
-("sbg_upfirdn2d_tail_supported", _c.c_int, [_c.POINTER(UpfirdnParams)]),
-        ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
+    ("sbg_upfirdn2d_tail_supported", _c.c_int, [_c.POINTER(UpfirdnParams)]),
+    ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
     ("sbg_conv2d_igemm_workspace", _c.c_int64, [_c.POINTER(ConvParams)]),
     ("sbg_conv2d_igemm", _c.c_int, [_c.POINTER(ConvParams), _c.c_void_p]),
     ("sbg_conv2d_wgrad_workspace", _c.c_int64, [_c.POINTER(WgradParams)]),
@@ -106,6 +117,9 @@ SYMBOLS = [
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_modconv_bwd_supported", _c.c_int, [_c.c_int]),
     ("sbg_modconv_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
+    ("sbg_grid_sample2d", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
+    ("sbg_grid_sample2d_bwd", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
+    ("sbg_filter1d_batch", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 8 + [_c.c_void_p]),
     ("sbg_prof_enable", _c.c_int, [_c.c_int]),
     ("sbg_prof_fetch", _c.c_int, [_c.POINTER(ProfRecord), _c.c_int]),
 ]

@@ -51,7 +51,8 @@ class StepEngine:
                  loss_arch='sg2', loss='softplus', loss_arch_kwargs=None, gen_regs=(), dis_regs=(('r1', dict(r1_gamma=10.)),),
                  optim_gen=('adam', dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)), optim_disc=('adam', dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)),
                  g_reg_interval=16, d_reg_interval=4, batch=64, batch_gpu=32, ema_kimg=10., ema_rampup=None, use_ema=True,
-                 world_size=1, rank=0, process_group=None, seed=0):
+                 world_size=1, rank=0, process_group=None, seed=0,
+                 augment_kwargs=None, augment_type='sg2_ada', augment_p=0.0, ada_target=None, ada_interval=4, ada_kimg=500):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self.batch, self.batch_gpu = batch, batch_gpu
@@ -78,6 +79,17 @@ class StepEngine:
             self.dp_modules = dict(G=GradReducer(self.G, **dp), D=GradReducer(self.D, **dp))
             la = dict(G=self.dp_modules['G'])
         la.update(loss_arch_kwargs or {})
+
+        # discriminator augmentation + the ADA heuristic's statistics (reference trainers.py:575-584)
+        self.augment_pipe, self.ada_stats = None, None
+        self.ada_target, self.ada_interval, self.ada_kimg = ada_target, ada_interval, ada_kimg
+        if augment_kwargs is not None and (augment_p > 0 or ada_target is not None):
+            from .augmentations import augmentations
+            self.augment_pipe = augmentations[augment_type](**augment_kwargs).train().requires_grad_(False).to(self.device)
+            self.augment_pipe.p.copy_(torch.as_tensor(float(augment_p)))
+            if ada_target is not None:
+                self.ada_stats = training_stats.Collector(regex='Loss/signs/real')
+            la['augment_pipe'] = self.augment_pipe
         # the fused training-time synthesis layer is first order only: generator regularisers (path length) differentiate twice
         from ..torch_utils.ops import modconv
         modconv.enabled = len(list(gen_regs)) == 0
@@ -135,6 +147,12 @@ class StepEngine:
                 self.update_ema()
         self.cur_nimg += self.batch * self.world_size
         self.batch_idx += 1
+
+        # ADA heuristic (reference :768-771): nudge the strength so that E[sign(D(real))] tracks `ada_target`
+        if self.ada_stats is not None and self.batch_idx % self.ada_interval == 0:
+            self.ada_stats.update()
+            adjust = np.sign(self.ada_stats['Loss/signs/real'] - self.ada_target) * (self.batch * self.world_size * self.ada_interval) / (self.ada_kimg * 1000)
+            self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp_(min=0))
 
     @torch.no_grad()
     def update_ema(self):
@@ -194,8 +212,7 @@ class BaseTrainer:
         batch_gpu = min(gen.batch_gpu, gen.batch // gpus)
         if gen.batch % gpus != 0 or gen.batch % (gpus * batch_gpu) != 0:
             raise ValueError("gen.batch must be a multiple of perf.gpus * gen.batch_gpu")
-        if config.aug.aug != "noaug":
-            raise NotImplementedError("ADA augmentation is outside this build's hot path: run with aug.aug=noaug")
+        self.aug = self._augment_arguments(config)
         if config.data.dataset != "synthetic":
             raise NotImplementedError("dataset loading is outside this build's hot path: run with data.dataset=synthetic "
                                       "(data.resolution=<R> data.num_classes=<K>)")
@@ -219,6 +236,40 @@ class BaseTrainer:
         self.ema_rampup = config.ema.ramp if config.ema.ramp >= 0 else None
         self.total_kimg = gen.kimg
         return self
+
+    @staticmethod
+    def _augment_arguments(config):
+        """aug.{aug, p, target, augpipe} -> StepEngine keywords (reference :295-335).  The reference looks `aug.augpipe` ('bgc', ...) up
+        in a registry that only holds the class name 'sg2_ada' (:335) and fails; the names mean the subsets of
+        stylegan2ada/train.py:271-283, which is what is resolved here."""
+        from .augmentations import augpipe_specs
+        aug = config.aug
+        out = dict(augment_kwargs=None, augment_type=aug.get("aug_type", "sg2_ada"), augment_p=0.0, ada_target=None, ada_interval=4, ada_kimg=500)
+        if aug.aug == "ada":
+            out["ada_target"] = 0.6
+        elif aug.aug == "fixed":
+            if aug.p < 0:
+                raise ValueError(f"--aug={aug.aug} requires specifying --p")
+        elif aug.aug != "noaug":
+            raise ValueError(f"--aug={aug.aug} not supported")
+        if aug.p >= 0:
+            if aug.aug != "fixed":
+                raise ValueError("--p can only be specified with --aug=fixed")
+            if not 0 <= aug.p <= 1:
+                raise ValueError("--p must be between 0 and 1")
+            out["augment_p"] = float(aug.p)
+        if aug.target >= 0:
+            if aug.aug != "ada":
+                raise ValueError("--target can only be specified with --aug=ada")
+            if not 0 <= aug.target <= 1:
+                raise ValueError("--target must be between 0 and 1")
+            out["ada_target"] = float(aug.target)
+        if aug.aug != "noaug":
+            if aug.augpipe not in augpipe_specs:
+                raise ValueError(f"aug.augpipe={aug.augpipe} not in {sorted(augpipe_specs)}")
+            base = config.get("augpipe_specs", {}).get(out["augment_type"], {})        # constructor arguments (std-devs, ranges) from the config
+            out["augment_kwargs"] = {**{k: v for k, v in dict(base).items() if k not in ("args", "kwargs")}, **augpipe_specs[aug.augpipe]}
+        return out
 
     @staticmethod
     def _model_kwargs(group, common):
@@ -260,14 +311,14 @@ class BaseTrainer:
                                  g_reg_interval=gen.g_reg_interval, d_reg_interval=gen.d_reg_interval,
                                  batch=self.batch_size // self.num_gpus, batch_gpu=self.batch_gpu, ema_kimg=self.config.ema.kimg,
                                  ema_rampup=self.ema_rampup, use_ema=self.config.ema.use_ema, world_size=self.num_gpus, rank=self.rank,
-                                 seed=gen.seed)
+                                 seed=gen.seed, **self.aug)
         if n_dis > 1:       # the generator phase runs every n_dis-th iteration (reference :609-610)
             for phase in self.engine.phases:
                 if phase.name.startswith("G"):
                     phase.interval = phase.interval * n_dis
 
     def setup_augmentations(self):
-        pass
+        self.augment_pipe = self.engine.augment_pipe        # built by StepEngine (it owns the loss object the pipe plugs into)
 
     def distrib_acrros_gpu(self):
         pass        # StepEngine wraps its modules in GradReducer at construction (broadcast of rank 0's weights included)

@@ -352,7 +352,51 @@ def gen_biggan():
     save("biggan_networks", arrays, cfg)
 
 
+# ---------------------------------------------------------------------------------------------------------------- ADA pipe
+
+AUG_SPECS = {   # stylegan2ada/train.py:271-283
+    "blit": dict(xflip=1, rotate90=1, xint=1),
+    "geom": dict(scale=1, rotate=1, aniso=1, xfrac=1),
+    "color": dict(brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1),
+    "filter": dict(imgfilter=1),
+    "noise": dict(noise=1),
+    "cutout": dict(cutout=1),
+}
+AUG_SPECS["bgc"] = {**AUG_SPECS["blit"], **AUG_SPECS["geom"], **AUG_SPECS["color"]}
+AUG_SPECS["bgcfnc"] = {**AUG_SPECS["bgc"], **AUG_SPECS["filter"], **AUG_SPECS["noise"], **AUG_SPECS["cutout"]}
+
+
+def gen_augment():
+    """the reference AugmentPipe (stylegan2ada/training/augment.py == train_parts/augmentations.py:121-433) on CPU: per case the
+    seed that precedes the call, the input images, the output, and d(sum(out * weight))/d(images)."""
+    from stylegan2ada.training import augment as R_aug
+    arrays, cases = {}, []
+    torch.manual_seed(104)
+    inputs = {"rgb": torch.randn(4, 3, 32, 32).clamp(-1, 1), "gray": torch.randn(3, 1, 24, 28).clamp(-1, 1)}
+    for k, v in inputs.items():
+        arrays[f"x/{k}"] = npy(v)
+    idx = 0
+    for spec, p, dbg, which in [("blit", 1.0, None, "rgb"), ("geom", 1.0, None, "rgb"), ("color", 1.0, None, "rgb"), ("filter", 1.0, None, "rgb"),
+                                ("noise", 1.0, None, "rgb"), ("cutout", 1.0, None, "rgb"), ("bgc", 1.0, None, "rgb"), ("bgc", 0.6, None, "rgb"),
+                                ("bgc", 0.0, None, "rgb"), ("bgcfnc", 0.8, None, "rgb"), ("bgcfnc", 1.0, None, "gray"), ("bgc", 0.7, None, "gray"),
+                                ("bgcfnc", 1.0, 0.3, "rgb"), ("bgc", 1.0, 0.85, "rgb")]:
+        pipe = R_aug.AugmentPipe(**AUG_SPECS[spec])
+        pipe.p.copy_(torch.as_tensor(p))
+        x = inputs[which].clone().requires_grad_(True)
+        seed = 5000 + idx
+        torch.manual_seed(seed)
+        y = pipe(x, debug_percentile=dbg)
+        wgt = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 1))
+        (dx,) = torch.autograd.grad((y * wgt).sum(), x)
+        arrays[f"y/{idx}"], arrays[f"dx/{idx}"], arrays[f"w/{idx}"] = npy(y), npy(dx), npy(wgt)
+        cases.append(dict(idx=idx, spec=spec, kwargs=AUG_SPECS[spec], p=p, debug_percentile=dbg, input=which, seed=seed))
+        idx += 1
+    arrays["Hz_fbank"] = npy(R_aug.AugmentPipe(imgfilter=1).Hz_fbank)
+    arrays["Hz_geom"] = npy(R_aug.AugmentPipe().Hz_geom)
+    save("augment", arrays, dict(cases=cases))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks", "biggan"]
+    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks", "biggan", "augment"]
     for name in which:
         globals()["gen_" + name]()

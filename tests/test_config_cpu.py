@@ -67,8 +67,15 @@ def test_trainer_validation(tmp_path):
     from style_big_gan_amd.train_parts.trainers import trainers
     argv = _write(tmp_path, "sg2ada.yaml", SG2ADA_LIKE)
     cfg = arguments.load_config(argv)
-    with pytest.raises(NotImplementedError, match="noaug"):       # ADA is out of scope; must be switched off explicitly
+    with pytest.raises(NotImplementedError, match="synthetic"):   # dataset loading is out of scope; must be switched explicitly
         trainers["sg2"]().setup_arguments(cfg)
+    ada = trainers["sg2"]().setup_arguments(arguments.load_config(argv + ["data.dataset=synthetic", "data.resolution=64"])).aug
+    assert ada["ada_target"] == 0.6 and ada["augment_p"] == 0.0 and ada["ada_interval"] == 4 and ada["augment_kwargs"]["hue"] == 1
+    assert sum(v == 1 for k, v in ada["augment_kwargs"].items() if k not in ("rotate_max", "hue_max", "saturation_std", "imgfilter_std")) == 12 and ada["augment_kwargs"]["xint_max"] == 0.125 and ada["augment_type"] == "sg2_ada"       # 'bgc' = blit + geom + color
+    fixed = trainers["sg2"]().setup_arguments(arguments.load_config(argv + ["data.dataset=synthetic", "aug.aug=fixed", "aug.p=0.3", "aug.augpipe=bg"])).aug
+    assert fixed["ada_target"] is None and fixed["augment_p"] == 0.3 and fixed["augment_kwargs"]["hue"] == 0 and fixed["augment_kwargs"]["xflip"] == 1
+    with pytest.raises(ValueError):
+        trainers["sg2"]().setup_arguments(arguments.load_config(argv + ["data.dataset=synthetic", "aug.p=0.3"]))
     cfg = arguments.load_config(argv + ["aug.aug=noaug", "data.dataset=synthetic", "data.resolution=64"])
     tr = trainers["sg2"]().setup_arguments(cfg)
     assert tr.batch_size == 64 and tr.batch_gpu == 32 and tr.dis_regs == [("r1", {"r1_gamma": 0.01})]
