@@ -42,7 +42,7 @@ def sg2ada_kwargs(res=RES, num_fp16_res=7, conv_clamp=256, channel_base=32768, m
     return gk, dk
 
 
-def build_engine(device, world_size, rank, batch=BATCH, batch_gpu=BATCH_GPU, res=RES):
+def build_engine(device, world_size, rank, batch=BATCH, batch_gpu=BATCH_GPU, res=RES, ada=None):
     from style_big_gan_amd.train_parts import trainers
     gk, dk = sg2ada_kwargs(res=res)
     return trainers.StepEngine(device, generator='sg2_classic', discriminator='sg2_classic', gen_kwargs=gk, disc_kwargs=dk,
@@ -51,7 +51,16 @@ def build_engine(device, world_size, rank, batch=BATCH, batch_gpu=BATCH_GPU, res
                                optim_gen=('adam', dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)),
                                optim_disc=('adam', dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)),
                                g_reg_interval=16, d_reg_interval=4, batch=batch, batch_gpu=batch_gpu,
-                               ema_kimg=500, ema_rampup=0.05, world_size=world_size, rank=rank, seed=0)
+                               ema_kimg=500, ema_rampup=0.05, world_size=world_size, rank=rank, seed=0, **ada_kwargs(ada))
+
+
+def ada_kwargs(ada):
+    """--ada P: the 'bgc' augmentation pipe in front of every discriminator call at starting strength P with the ADA heuristic
+    (target 0.6) running -- a secondary measurement; the headline metric is quoted with ADA off."""
+    if ada is None:
+        return {}
+    from style_big_gan_amd.train_parts.augmentations import augpipe_specs
+    return dict(augment_kwargs=dict(augpipe_specs['bgc']), augment_p=float(ada), ada_target=0.6, ada_interval=4, ada_kimg=500)
 
 
 def summarize_kernels(records):
@@ -131,6 +140,7 @@ def main():
     ap.add_argument('--res', type=int, default=RES, help='debug only; the benchmark is 256')
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--batch-gpu', type=int, default=BATCH_GPU)
+    ap.add_argument('--ada', type=float, default=None, metavar='P', help="secondary measurement: 'bgc' ADA pipe on, starting strength P (headline = off)")
     ap.add_argument('--kernel-breakdown', action='store_true', help='print the per-kernel launch log summary to stderr')
     args = ap.parse_args()
 
@@ -151,7 +161,7 @@ def main():
     import style_big_gan_amd
     from style_big_gan_amd import _lib
     _lib.load()
-    eng = build_engine(device, world, rank, batch=args.batch, batch_gpu=args.batch_gpu, res=args.res)
+    eng = build_engine(device, world, rank, batch=args.batch, batch_gpu=args.batch_gpu, res=args.res, ada=args.ada)
     gen = torch.Generator(device=device); gen.manual_seed(1234 + rank)
     real_u8 = torch.randint(0, 256, [args.batch, 3, args.res, args.res], device=device, dtype=torch.uint8, generator=gen)
 
@@ -234,7 +244,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'configs/sg2ada.yaml @ {args.res}x{args.res}: sg2_classic G (skip) + D (orig), softplus + R1(0.01)/4, '
-                                   f'batch {args.batch}/rank = {args.batch // args.batch_gpu} x batch_gpu {args.batch_gpu}, num_fp16_res 7 (bf16), conv_clamp 256, ADA off',
+                                   f'batch {args.batch}/rank = {args.batch // args.batch_gpu} x batch_gpu {args.batch_gpu}, num_fp16_res 7 (bf16), conv_clamp 256, '
+                                   + ('ADA off' if args.ada is None else f'ADA bgc on (p0 = {args.ada}, target 0.6; secondary measurement)'),
                        'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
             'roofline': roofline, 'target_kernel': target, 'cpu_baseline': cpu,
             'kernel_ms_per_step': {k: v['ms_per_step'] for k, v in breakdown.items()},

@@ -83,6 +83,14 @@ typedef struct sbg_upfirdn2d_params {
 int sbg_upfirdn2d_tail_supported(const sbg_upfirdn2d_params* p);
 int sbg_upfirdn2d(const sbg_upfirdn2d_params* p, sbg_stream_t stream);
 
+/* Separable filter (1-D `f` of `taps` taps applied along both axes) in one launch -- replaces the reference's two plugin calls
+ * with sqrt(gain) each for a rank-1 filter (stylegan2ada/torch_utils/ops/upfirdn2d.py:236-240).  Dense planar fp32 planes
+ * x [M, IH, IW] -> y [M, OH, OW]; up, down in {1, 2} on both axes; OH = (IH*up + pady0 + pady1 - taps) / down + 1 etc. is the
+ * caller's to compute (as for sbg_upfirdn2d); `gain` is the total gain.  _supported() says whether (up, down, taps) fits. */
+int sbg_upfirdn2d_separable_supported(int up, int down, int taps);
+int sbg_upfirdn2d_separable(const float* x, const float* f, float* y, int M, int IH, int IW, int OH, int OW, int taps,
+                            int up, int down, int padx0, int pady0, int flip, float gain, sbg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on MFMA (channels-last activations).
  * Replaces the aten/cuDNN calls behind `conv2d_gradfix.conv2d / conv_transpose2d`
@@ -230,9 +238,14 @@ typedef struct sbg_grid_sample_params {
     int N, C, IH, IW, OH, OW;
     int64_t xs_n, xs_c, xs_h, xs_w;
     int64_t ys_n, ys_c, ys_h, ys_w;
+    const float* theta_host;            /* optional HOST copy of theta: lets _bwd pick the deterministic gather kernel */
 } sbg_grid_sample_params;
 int sbg_grid_sample2d(const sbg_grid_sample_params* p, sbg_stream_t stream);
 int sbg_grid_sample2d_bwd(const sbg_grid_sample_params* p, sbg_stream_t stream);
+/* 1 when _bwd will take the gather kernel for these parameters: affine positions (theta + theta_host, no grid, no dgrid, C <= 4)
+ * whose per-pixel candidate box is small.  That kernel OVERWRITES every element of dx (no zero fill needed, no atomics, bitwise
+ * reproducible); otherwise _bwd accumulates into a caller-zeroed dx with fp32 atomics. */
+int sbg_grid_sample2d_bwd_overwrites(const sbg_grid_sample_params* p);
 
 /* Per-sample 1-D correlation of M dense fp32 planes [M, H, W] along W (axis 0) or H (axis 1):
  *   y[m, .., o] = sum_t x[m, .., o + t - pad] * taps[m / planes_per_filter][flip ? T-1-t : t]      (zeros outside)

@@ -80,6 +80,7 @@ class GridSampleParams(ctypes.Structure):
         ("N", ctypes.c_int), ("C", ctypes.c_int), ("IH", ctypes.c_int), ("IW", ctypes.c_int), ("OH", ctypes.c_int), ("OW", ctypes.c_int),
         ("xs_n", ctypes.c_int64), ("xs_c", ctypes.c_int64), ("xs_h", ctypes.c_int64), ("xs_w", ctypes.c_int64),
         ("ys_n", ctypes.c_int64), ("ys_c", ctypes.c_int64), ("ys_h", ctypes.c_int64), ("ys_w", ctypes.c_int64),
+        ("theta_host", ctypes.c_void_p),
     ]
 
 
@@ -103,6 +104,8 @@ SYMBOLS = [
                                                    _c.c_int64, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_upfirdn2d_tail_supported", _c.c_int, [_c.POINTER(UpfirdnParams)]),
     ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
+    ("sbg_upfirdn2d_separable_supported", _c.c_int, [_c.c_int] * 3),
+    ("sbg_upfirdn2d_separable", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 11 + [_c.c_float, _c.c_void_p]),
     ("sbg_conv2d_igemm_workspace", _c.c_int64, [_c.POINTER(ConvParams)]),
     ("sbg_conv2d_igemm", _c.c_int, [_c.POINTER(ConvParams), _c.c_void_p]),
     ("sbg_conv2d_wgrad_workspace", _c.c_int64, [_c.POINTER(WgradParams)]),
@@ -119,6 +122,7 @@ SYMBOLS = [
     ("sbg_modconv_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
     ("sbg_grid_sample2d", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
+    ("sbg_grid_sample2d_bwd_overwrites", _c.c_int, [_c.POINTER(GridSampleParams)]),
     ("sbg_filter1d_batch", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 8 + [_c.c_void_p]),
     ("sbg_prof_enable", _c.c_int, [_c.c_int]),
     ("sbg_prof_fetch", _c.c_int, [_c.POINTER(ProfRecord), _c.c_int]),

@@ -8,6 +8,7 @@
 // All three are HBM-bound streaming kernels over planar fp32 images with 1 or 3 channels: one lane per output pixel, lanes of
 // a wavefront along W (coalesced 256-B rows), channel loop inside the lane so index math and weights are computed once.
 #include "sbg_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
@@ -93,10 +94,10 @@ __global__ void __launch_bounds__(256) grid_sample_bwd_kernel(GridArgs p)
             const float g = dyb[(int64_t)c * p.ys_c];
             const int64_t oc = off + (int64_t)c * p.xs_c;
             if (p.dx) {
-                if (vy0 && vx0) atomicAdd(p.dx + oc, w00 * g);
-                if (vy0 && vx1) atomicAdd(p.dx + oc + p.xs_w, w01 * g);
-                if (vy1 && vx0) atomicAdd(p.dx + oc + p.xs_h, w10 * g);
-                if (vy1 && vx1) atomicAdd(p.dx + oc + p.xs_h + p.xs_w, w11 * g);
+                if (vy0 && vx0) unsafeAtomicAdd(p.dx + oc, w00 * g);
+                if (vy0 && vx1) unsafeAtomicAdd(p.dx + oc + p.xs_w, w01 * g);
+                if (vy1 && vx0) unsafeAtomicAdd(p.dx + oc + p.xs_h, w10 * g);
+                if (vy1 && vx1) unsafeAtomicAdd(p.dx + oc + p.xs_h + p.xs_w, w11 * g);
             }
             if (p.dgrid) {
                 const float* xc = p.x + oc;
@@ -112,6 +113,81 @@ __global__ void __launch_bounds__(256) grid_sample_bwd_kernel(GridArgs p)
             dg[1] = giy * (float)p.IH * 0.5f;
         }
     }
+}
+
+
+// Deterministic backward for affine sampling positions: one lane per INPUT pixel gathers from the output pixels whose bilinear
+// footprint covers it.  Output pixel o samples at P(o) = A o + b (affine), so the candidates of input pixel i are the integer
+// points of the parallelogram A^-1 ((i - b) + (-1, 1)^2); its bounding box is walked and every candidate re-evaluates P(o) with
+// the forward kernel's own expression, so the weights agree with the forward pass to rounding.  No atomics, no zero fill, and
+// neighbouring lanes read overlapping dy windows (L1 / L2 hits).  ex / ey: half extents of the bounding box, computed by the
+// launcher from the host copy of theta (which also bounds the loop: the launcher refuses boxes larger than GATHER_MAX_BOX).
+#define GATHER_MAX_BOX 24
+#define GATHER_MAX_C 4
+__global__ void __launch_bounds__(256) grid_sample_bwd_gather_kernel(GridArgs p)
+{
+    const int64_t total = (int64_t)p.N * p.IH * p.IW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % p.IW);
+        const int iy = (int)((i / p.IW) % p.IH);
+        const int n  = (int)(i / ((int64_t)p.IW * p.IH));
+        const float* t = p.theta + (int64_t)n * 6;
+        const float a00 = t[0] * (float)p.IW / (float)p.OW, a01 = t[1] * (float)p.IW / (float)p.OH;
+        const float a10 = t[3] * (float)p.IH / (float)p.OW, a11 = t[4] * (float)p.IH / (float)p.OH;
+        float b0, b1;
+        sample_pos(p, n, 0, 0, b0, b1);
+        const float det = a00 * a11 - a01 * a10;
+        const float r = 1.0f / det;
+        const float i00 = a11 * r, i01 = -a01 * r, i10 = -a10 * r, i11 = a00 * r;
+        const float dx_ = (float)ix - b0, dy_ = (float)iy - b1;
+        const float ocx = i00 * dx_ + i01 * dy_, ocy = i10 * dx_ + i11 * dy_;
+        const float ex = fabsf(i00) + fabsf(i01) + 0.01f, ey = fabsf(i10) + fabsf(i11) + 0.01f;
+        float acc[GATHER_MAX_C];
+#pragma unroll
+        for (int c = 0; c < GATHER_MAX_C; c++) acc[c] = 0.0f;
+        // (NaN / inf from a singular theta fail every comparison below and leave empty loops)
+        int ox0 = (ocx - ex > -1.0f) ? (int)floorf(fminf(ocx - ex, (float)p.OW)) : -1;
+        int oy0 = (ocy - ey > -1.0f) ? (int)floorf(fminf(ocy - ey, (float)p.OH)) : -1;
+        int ox1 = (ocx + ex < (float)p.OW) ? (int)ceilf(fmaxf(ocx + ex, -1.0f)) : p.OW;
+        int oy1 = (ocy + ey < (float)p.OH) ? (int)ceilf(fmaxf(ocy + ey, -1.0f)) : p.OH;
+        ox0 = max(ox0, 0); oy0 = max(oy0, 0); ox1 = min(ox1, p.OW - 1); oy1 = min(oy1, p.OH - 1);
+        ox1 = min(ox1, ox0 + GATHER_MAX_BOX); oy1 = min(oy1, oy0 + GATHER_MAX_BOX);        // hard bound; the launcher guarantees it is never hit
+        for (int oy = oy0; oy <= oy1; oy++) {
+            for (int ox = ox0; ox <= ox1; ox++) {
+                float px, py;
+                sample_pos(p, n, oy, ox, px, py);
+                const float wx = 1.0f - fabsf(px - (float)ix), wy = 1.0f - fabsf(py - (float)iy);
+                if (wx > 0.0f && wy > 0.0f) {
+                    const float w = wx * wy;
+                    const float* d = p.dy + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
+#pragma unroll
+                    for (int c = 0; c < GATHER_MAX_C; c++)
+                        if (c < p.C) acc[c] += w * d[(int64_t)c * p.ys_c];
+                }
+            }
+        }
+        float* o = p.dx + (int64_t)n * p.xs_n + (int64_t)iy * p.xs_h + (int64_t)ix * p.xs_w;
+#pragma unroll
+        for (int c = 0; c < GATHER_MAX_C; c++)
+            if (c < p.C) o[(int64_t)c * p.xs_c] = acc[c];
+    }
+}
+
+// largest candidate box (in output pixels, per axis) over the batch, from the host copy of theta; 0 = do not use the gather kernel
+static int gather_box(const float* th, int N, int IH, int IW, int OH, int OW)
+{
+    float worst = 0.0f;
+    for (int n = 0; n < N; n++) {
+        const float* t = th + (size_t)n * 6;
+        const float a00 = t[0] * IW / OW, a01 = t[1] * IW / OH, a10 = t[3] * IH / OW, a11 = t[4] * IH / OH;
+        const float det = a00 * a11 - a01 * a10;
+        if (!(fabsf(det) > 1e-12f)) return 0;
+        const float ex = (fabsf(a11) + fabsf(a01)) / fabsf(det), ey = (fabsf(a10) + fabsf(a00)) / fabsf(det);
+        if (!(ex < 1e6f && ey < 1e6f)) return 0;
+        worst = fmaxf(worst, fmaxf(ex, ey));
+    }
+    const int box = 2 * (int)ceilf(worst + 0.01f) + 2;
+    return box <= GATHER_MAX_BOX ? box : 0;
 }
 
 struct FiltArgs {
@@ -180,6 +256,12 @@ extern "C" int sbg_grid_sample2d(const sbg_grid_sample_params* p, sbg_stream_t s
     return 0;
 }
 
+extern "C" int sbg_grid_sample2d_bwd_overwrites(const sbg_grid_sample_params* p)
+{
+    if (!p || !p->theta || !p->theta_host || p->grid || p->dgrid || !p->dx || p->C > GATHER_MAX_C || p->N <= 0) return 0;
+    return gather_box(p->theta_host, p->N, p->IH, p->IW, p->OH, p->OW) > 0 ? 1 : 0;
+}
+
 extern "C" int sbg_grid_sample2d_bwd(const sbg_grid_sample_params* p, sbg_stream_t stream_)
 {
     GridArgs a;
@@ -190,6 +272,13 @@ extern "C" int sbg_grid_sample2d_bwd(const sbg_grid_sample_params* p, sbg_stream
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t total = (int64_t)a.N * a.OH * a.OW;
     const double bytes = 4.0 * ((double)total * a.C + (a.dx ? 2.0 : 1.0) * (double)a.N * a.C * a.IH * a.IW + (a.grid ? 2.0 * total : 0.0));
+    if (sbg_grid_sample2d_bwd_overwrites(p)) {
+        SbgProfScope prof(stream, SBG_K_GRID_SAMPLE, 0.0, bytes, {a.N, a.C, a.IH, a.IW, a.OH, a.OW, 2});
+        const int64_t in_total = (int64_t)a.N * a.IH * a.IW;
+        hipLaunchKernelGGL(grid_sample_bwd_gather_kernel, dim3((unsigned)((in_total + 255) / 256)), dim3(256), 0, stream, a);
+        SBG_HIP_LAUNCH_CHECK();
+        return 0;
+    }
     SbgProfScope prof(stream, SBG_K_GRID_SAMPLE, 0.0, bytes, {a.N, a.C, a.IH, a.IW, a.OH, a.OW, 1});
     hipLaunchKernelGGL(grid_sample_bwd_kernel, dim3(sbg_stream_grid(total, 256)), dim3(256), 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();

@@ -68,12 +68,15 @@ def _gather(x, g, t, oh, ow):
     return y
 
 
-def _scatter(dy, x_shape, g, t, x=None, want_dx=True):
+def _scatter(dy, x_shape, g, t, x=None, want_dx=True, theta_host=None):
     """-> (dx or None, dgrid or None); dgrid only when x is given"""
+    lib = _lib.load()
     dy = _f32(dy)
-    dx = torch.zeros(x_shape, dtype=torch.float32, device=dy.device) if want_dx else None
+    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device) if want_dx else None
     dgrid = torch.empty([dy.shape[0], dy.shape[2], dy.shape[3], 2], dtype=torch.float32, device=dy.device) if x is not None else None
-    if dy.numel() and (want_dx or x is not None):
+    launch = dy.numel() and (want_dx or x is not None)
+    overwrites = False
+    if launch:
         ref = dx if dx is not None else x
         p = _params(ref, dy, g, t)
         p.dy = dy.data_ptr()
@@ -82,20 +85,28 @@ def _scatter(dy, x_shape, g, t, x=None, want_dx=True):
         if x is not None:
             assert x.stride() == ref.stride()
             p.x, p.dgrid = x.data_ptr(), dgrid.data_ptr()
-        _lib.check(_lib.load().sbg_grid_sample2d_bwd(p, _lib.stream_ptr(dy.device)), "sbg_grid_sample2d_bwd")
+        if theta_host is not None and t is not None:
+            assert theta_host.device.type == "cpu" and theta_host.dtype == torch.float32 and theta_host.is_contiguous() and theta_host.shape == t.shape
+            p.theta_host = theta_host.data_ptr()
+        overwrites = bool(lib.sbg_grid_sample2d_bwd_overwrites(p))      # deterministic gather kernel: writes every element of dx
+    if dx is not None and not overwrites:
+        dx.zero_()
+    if launch:
+        _lib.check(lib.sbg_grid_sample2d_bwd(p, _lib.stream_ptr(dy.device)), "sbg_grid_sample2d_bwd")
     return dx, dgrid
 
 
 class _GridSampleForward(torch.autograd.Function):
-    """(input, grid | None, theta | None, oh, ow) -> output"""
+    """(input, grid | None, theta | None, oh, ow, theta_host | None) -> output"""
 
     @staticmethod
-    def forward(ctx, input, grid, theta, oh, ow):
+    def forward(ctx, input, grid, theta, oh, ow, theta_host=None):
         g, t = _positions(grid, theta)
         y = _gather(input, g, t, oh, ow)
         ctx.save_for_backward(input if (grid is not None and grid.requires_grad) else None, g, t)
         ctx.x_shape, ctx.x_dtype = tuple(input.shape), input.dtype
         ctx.grid_dtype = grid.dtype if grid is not None else None
+        ctx.theta_host = theta_host
         return y.to(input.dtype)
 
     @staticmethod
@@ -103,7 +114,7 @@ class _GridSampleForward(torch.autograd.Function):
         x, g, t = ctx.saved_tensors
         grad_input = grad_grid = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            grad_input, grad_grid = _GridSampleBackward.apply(grad_output, x, g, t, ctx.x_shape, ctx.needs_input_grad[0])
+            grad_input, grad_grid = _GridSampleBackward.apply(grad_output, x, g, t, ctx.x_shape, ctx.needs_input_grad[0], ctx.theta_host)
             if grad_input is not None:
                 grad_input = grad_input.to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
@@ -113,17 +124,18 @@ class _GridSampleForward(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             raise RuntimeError("affine_grid_sample: the gradient with respect to theta is not implemented "
                                "(the augmentation pipe's transforms carry no gradient)")
-        return grad_input, grad_grid, None, None, None
+        return grad_input, grad_grid, None, None, None, None
 
 
 class _GridSampleBackward(torch.autograd.Function):
-    """(grad_output, input | None, grid, theta, x_shape, want_dx) -> (grad_input, grad_grid)"""
+    """(grad_output, input | None, grid, theta, x_shape, want_dx, theta_host) -> (grad_input, grad_grid)"""
 
     @staticmethod
-    def forward(ctx, grad_output, x, g, t, x_shape, want_dx):
+    def forward(ctx, grad_output, x, g, t, x_shape, want_dx, theta_host=None):
         xd = _f32(x.detach()).contiguous() if x is not None else None      # dense, so it shares dx's strides
-        dx, dgrid = _scatter(grad_output, x_shape, g, t, x=xd, want_dx=want_dx or xd is None)
+        dx, dgrid = _scatter(grad_output, x_shape, g, t, x=xd, want_dx=want_dx or xd is None, theta_host=theta_host)
         ctx.save_for_backward(g, t)
+        ctx.theta_host = theta_host
         ctx.oh, ctx.ow = grad_output.shape[2], grad_output.shape[3]
         ctx.mark_non_differentiable(*([dgrid] if dgrid is not None else []))
         return dx, dgrid
@@ -133,18 +145,21 @@ class _GridSampleBackward(torch.autograd.Function):
         g, t = ctx.saved_tensors
         grad2_grad_output = None
         if ctx.needs_input_grad[0] and grad2_grad_input is not None:
-            grad2_grad_output = _GridSampleForward.apply(grad2_grad_input, g, t, ctx.oh, ctx.ow)
+            grad2_grad_output = _GridSampleForward.apply(grad2_grad_input, g, t, ctx.oh, ctx.ow, ctx.theta_host)
         # like the reference (:70-79): the second-order terms through `input` and `grid` (they exist only via grad_grid) are not produced
-        return grad2_grad_output, None, None, None, None, None
+        return grad2_grad_output, None, None, None, None, None, None
 
 
 def grid_sample(input, grid):
     """reference: grid_sample_gradfix.grid_sample(input, grid) (:24-27)"""
     oh, ow = _check(input, grid, None, None)
-    return _GridSampleForward.apply(input, grid, None, oh, ow)
+    return _GridSampleForward.apply(input, grid, None, oh, ow, None)
 
 
-def affine_grid_sample(input, theta, size):
-    """grid_sample(input, affine_grid(theta, size, align_corners=False)) in one kernel; theta: [N, 2, 3]."""
+def affine_grid_sample(input, theta, size, theta_host=None):
+    """grid_sample(input, affine_grid(theta, size, align_corners=False)) in one kernel; theta: [N, 2, 3] on the device.
+    `theta_host`: the same values as a contiguous float32 CPU tensor, when the caller has them (the augmentation pipe composes its
+    transforms on the host): the backward pass can then prove the per-pixel footprint small and run as a gather -- no atomics,
+    no zero fill, bitwise reproducible -- instead of an atomic scatter."""
     oh, ow = _check(input, None, theta, size)
-    return _GridSampleForward.apply(input, None, theta, oh, ow)
+    return _GridSampleForward.apply(input, None, theta, oh, ow, theta_host)

@@ -122,6 +122,27 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     return y
 
 
+def _separable_fused_ok(x, f, upx, upy, downx, downy):
+    """planar dense fp32 image, same factor on both axes: both passes of a rank-1 filter run in one launch (sbg_upfirdn2d_separable)"""
+    return (x.dtype == torch.float32 and x.is_contiguous() and upx == upy and downx == downy and f.dtype == torch.float32
+            and bool(_lib.load().sbg_upfirdn2d_separable_supported(upx, downx, f.numel())))
+
+
+def _launch_separable(x, f, up, down, padx0, padx1, pady0, pady1, flip, gain):
+    n, c, ih, iw = x.shape
+    t = f.numel()
+    ow = (iw * up + padx0 + padx1 - t) // down + 1
+    oh = (ih * up + pady0 + pady1 - t) // down + 1
+    if ow < 1 or oh < 1:
+        raise RuntimeError("upfirdn2d: output would be empty")
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
+    fc = f.contiguous()
+    if y.numel():
+        _lib.check(_lib.load().sbg_upfirdn2d_separable(x.data_ptr(), fc.data_ptr(), y.data_ptr(), n * c, ih, iw, oh, ow, t, up, down,
+                                                       padx0, pady0, int(bool(flip)), float(gain), _lib.stream_ptr(x.device)), "sbg_upfirdn2d_separable")
+    return y
+
+
 _exact_cache = {}
 
 
@@ -149,6 +170,8 @@ class _Upfirdn2d(torch.autograd.Function):
         assert f.ndim in [1, 2]
         if f.ndim == 2:
             y = _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+        elif _separable_fused_ok(x, f, upx, upy, downx, downy):
+            y = _launch_separable(x, f, upx, downx, padx0, padx1, pady0, pady1, flip, gain)
         else:   # separable: a row pass then a column pass, sqrt(gain) each
             g = float(np.sqrt(gain))
             y = _launch(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip, g)

@@ -372,7 +372,8 @@ class AugmentPipe(torch.nn.Module):
             images = upfirdn2d.upsample2d(x=images, f=self.Hz_geom, up=2)
             assert tuple(images.shape[2:]) == tuple(params['up_shape'])
             theta = dev['theta'].reshape(n, 2, 3).contiguous()
-            images = grid_sample_gradfix.affine_grid_sample(images, theta, params['grid_shape'])
+            images = grid_sample_gradfix.affine_grid_sample(images, theta, params['grid_shape'],
+                                                            theta_host=params['theta'].to(torch.float32).expand(n, 2, 3).contiguous())
             images = upfirdn2d.downsample2d(x=images, f=self.Hz_geom, down=2, padding=-params['hz_pad'] * 2, flip_filter=True)
 
         if 'color' in params:

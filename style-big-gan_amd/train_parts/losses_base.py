@@ -49,13 +49,19 @@ class LossBase:
         with torch.autograd.profiler.record_function('Gmain_backward'):
             loss_Gmain.mul(gain).backward()
 
-    def do_Dmain(self, real_img, real_c, gen_z, gen_c, sync, gain):
+    def do_Dmain(self, real_img, real_c, gen_z, gen_c, sync, gain, need_real_grad=None):
         with torch.autograd.profiler.record_function('Dgen_forward'):
             gen_img = self.run_G(gen_z, gen_c, sync=False)
             gen_logits = self.run_D(gen_img, gen_c, sync=False)     # synced by the real pass below
             training_stats.report('Loss/scores/fake', gen_logits)
             training_stats.report('Loss/signs/fake', gen_logits.sign())
-            real_img_tmp = real_img.detach().requires_grad_(self.dis_regs is not None)
+            # The reference marks the reals as requiring grad whenever a discriminator regulariser is configured (:71), so a plain
+            # 'Dmain' phase also back-propagates to the image (first-layer data gradient + the augmentation pipe's backward) and
+            # discards the result.  Only a regulariser in the SAME phase ('Dboth') reads that graph; otherwise it is dead work and
+            # is not scheduled here.  Parameter gradients are unaffected.
+            if need_real_grad is None:
+                need_real_grad = self.dis_regs is not None
+            real_img_tmp = real_img.detach().requires_grad_(bool(need_real_grad))
             real_logits = self.run_D(real_img_tmp, real_c, sync=sync)
             training_stats.report('Loss/scores/real', real_logits)
             training_stats.report('Loss/signs/real', real_logits.sign())
@@ -79,7 +85,7 @@ class LossBase:
 
         real_logits = real_img_tmp = None
         if do_Dmain:
-            real_logits, real_img_tmp = self.do_Dmain(real_img, real_c, gen_z, gen_c, sync=(sync and not do_Dreg), gain=gain)
+            real_logits, real_img_tmp = self.do_Dmain(real_img, real_c, gen_z, gen_c, sync=(sync and not do_Dreg), gain=gain, need_real_grad=do_Dreg)
         if do_Dreg:
             if not do_Dmain:
                 with torch.autograd.profiler.record_function('Dreg_forward'):

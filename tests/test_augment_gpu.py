@@ -139,3 +139,29 @@ def test_pipe_forward_at_benchmark_shape(dev):
     pipe.p.copy_(torch.as_tensor(0.0))          # strength 0: every transform is the identity; the orthogonal sym6 round trip reconstructs
     y0 = pipe(x.detach())
     assert max_rel(y0, x) < 2e-2
+
+
+def test_training_step_with_ada(dev):
+    """StepEngine with the pipe in front of D and the ADA heuristic running (reference trainers.py:575-584, 768-771)"""
+    from style_big_gan_amd.torch_utils import training_stats
+    from style_big_gan_amd.train_parts import trainers
+    gk = dict(z_dim=64, c_dim=0, w_dim=64, img_resolution=32, img_channels=3, mapping_kwargs=dict(num_layers=2),
+              synthesis_kwargs=dict(channel_base=1024, channel_max=64, num_fp16_res=2, block_kwargs=dict(conv_clamp=256)))
+    dk = dict(c_dim=0, img_resolution=32, img_channels=3, architecture='orig', channel_base=1024, channel_max=64, num_fp16_res=2,
+              conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=4))
+    training_stats.init_multiprocessing(rank=0, sync_device=None)
+    eng = trainers.StepEngine(dev, gen_kwargs=gk, disc_kwargs=dk, loss_arch_kwargs=dict(style_mixing_prob=0), dis_regs=[('r1', dict(r1_gamma=0.01))],
+                              d_reg_interval=2, batch=8, batch_gpu=4, augment_kwargs=dict(A.augpipe_specs['bgc']), augment_p=0.2,
+                              ada_target=0.6, ada_interval=2, ada_kimg=0.1)
+    assert eng.augment_pipe is not None and eng.loss.augment_pipe is eng.augment_pipe and abs(float(eng.augment_pipe.p) - 0.2) < 1e-6
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    strengths = []
+    for _ in range(4):
+        real = torch.rand([8, 3, 32, 32], device=dev, generator=gen) * 2 - 1
+        eng.train_iteration(real, None)
+        strengths.append(float(eng.augment_pipe.p))
+    step = 8 * 2 / (0.1 * 1000)
+    assert strengths[0] == pytest.approx(0.2)                                       # no adjustment before `ada_interval` iterations
+    assert abs(abs(strengths[1] - 0.2) - step) < 1e-5                               # then one step of batch * interval / (ada_kimg * 1000), up or down
+    assert abs(abs(strengths[3] - strengths[1]) - step) < 1e-5 or strengths[3] == 0.0
+    assert all(torch.isfinite(p).all() for p in list(eng.G.parameters()) + list(eng.D.parameters()))
