@@ -247,6 +247,11 @@ int sbg_grid_sample2d_bwd(const sbg_grid_sample_params* p, sbg_stream_t stream);
  * reproducible); otherwise _bwd accumulates into a caller-zeroed dx with fp32 atomics. */
 int sbg_grid_sample2d_bwd_overwrites(const sbg_grid_sample_params* p);
 
+/* Per-sample colour transform of dense planar fp32 RGB images x [N, 3, HW]: y[n, c, :] = sum_c' M[n, c, c'] x[n, c', :] + M[n, c, 3]
+ * with M fp32 [N, 3, 4] -- `C[:, :3, :3] @ images + C[:, :3, 3:]` (augmentations.py:352-354).  Its data gradient is the same call
+ * with the transposed 3x3 block and a zero fourth column. */
+int sbg_color_transform(const float* x, const float* M, float* y, int N, int64_t HW, sbg_stream_t stream);
+
 /* Per-sample 1-D correlation of M dense fp32 planes [M, H, W] along W (axis 0) or H (axis 1):
  *   y[m, .., o] = sum_t x[m, .., o + t - pad] * taps[m / planes_per_filter][flip ? T-1-t : t]      (zeros outside)
  * = one of the two grouped convolutions of the image-space filter, `conv2d(images, Hz_prime.unsqueeze(2 or 3),
@@ -263,7 +268,7 @@ int sbg_filter1d_batch(const float* x, const float* taps, float* y, int M, int H
  * (or the number pending when out == NULL). */
 enum sbg_kernel_kind {
     SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
-    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13
 };
 typedef struct sbg_prof_record {
     int    kind;            /* enum sbg_kernel_kind */

@@ -90,7 +90,7 @@ class ProfRecord(ctypes.Structure):
 
 
 KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 9: "sn_power", 10: "attention",
-                11: "grid_sample", 12: "filter1d"}
+                11: "grid_sample", 12: "filter1d", 13: "color"}
 
 _lib = None
 _lock = threading.Lock()
@@ -123,6 +123,7 @@ SYMBOLS = [
     ("sbg_grid_sample2d", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd_overwrites", _c.c_int, [_c.POINTER(GridSampleParams)]),
+    ("sbg_color_transform", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_filter1d_batch", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 8 + [_c.c_void_p]),
     ("sbg_prof_enable", _c.c_int, [_c.c_int]),
     ("sbg_prof_fetch", _c.c_int, [_c.POINTER(ProfRecord), _c.c_int]),

@@ -190,6 +190,37 @@ static int gather_box(const float* th, int N, int IH, int IW, int OH, int OW)
     return box <= GATHER_MAX_BOX ? box : 0;
 }
 
+// y[n, c, i] = sum_c' M[n, c, c'] * x[n, c', i] + M[n, c, 3]: the per-sample 3x4 colour transform (augmentations.py:352-354) as
+// one streaming pass (the reference's batched [3x3] @ [3, HW] matmul maps badly onto GEMM tiles), 4 pixels per lane.
+__global__ void __launch_bounds__(256) color_transform_kernel(const float* __restrict__ x, const float* __restrict__ M, float* __restrict__ y,
+                                                              int N, int64_t HW, int64_t quads_per_image)
+{
+    const int64_t total = (int64_t)N * quads_per_image;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / quads_per_image);
+        const int64_t q = (i - (int64_t)n * quads_per_image) * 4;
+        const float* m = M + (int64_t)n * 12;
+        const float* xb = x + (int64_t)n * 3 * HW + q;
+        float* yb = y + (int64_t)n * 3 * HW + q;
+        if (q + 4 <= HW && ((HW & 3) == 0)) {
+            const float4_t r = *reinterpret_cast<const float4_t*>(xb), g = *reinterpret_cast<const float4_t*>(xb + HW),
+                           b = *reinterpret_cast<const float4_t*>(xb + 2 * HW);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float4_t o;
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] = m[c * 4 + 0] * r[j] + m[c * 4 + 1] * g[j] + m[c * 4 + 2] * b[j] + m[c * 4 + 3];
+                *reinterpret_cast<float4_t*>(yb + c * HW) = o;
+            }
+        } else {
+            for (int j = 0; j < 4 && q + j < HW; j++) {
+                const float r = xb[j], g = xb[HW + j], b = xb[2 * HW + j];
+                for (int c = 0; c < 3; c++) yb[c * HW + j] = m[c * 4 + 0] * r + m[c * 4 + 1] * g + m[c * 4 + 2] * b + m[c * 4 + 3];
+            }
+        }
+    }
+}
+
 struct FiltArgs {
     const float* x; const float* taps; float* y;
     int M, H, W, OH, OW, T, axis, pad, planes_per_filter, flip;
@@ -302,6 +333,19 @@ extern "C" int sbg_filter1d_batch(const float* x, const float* taps, float* y, i
     const int64_t total = (int64_t)M * a.OH * a.OW;
     SbgProfScope prof(stream, SBG_K_FILTER1D, 0.0, 4.0 * ((double)M * H * W + (double)total), {M, H, W, T, axis, pad, 0});
     hipLaunchKernelGGL(filter1d_batch_kernel, dim3(sbg_stream_grid(total, 256)), dim3(256), 0, stream, a);
+    SBG_HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sbg_color_transform(const float* x, const float* M, float* y, int N, int64_t HW, sbg_stream_t stream_)
+{
+    SBG_CHECK(x && M && y, "color_transform: null pointer");
+    SBG_CHECK(N >= 0 && HW >= 1 && (int64_t)N * 3 * HW <= INT32_MAX, "color_transform: bad sizes");
+    if (N == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t quads = (HW + 3) / 4;
+    SbgProfScope prof(stream, SBG_K_COLOR, 0.0, 4.0 * 6.0 * (double)N * HW, {N, 3, (int)HW, 0, 0, 0, 0});
+    hipLaunchKernelGGL(color_transform_kernel, dim3(sbg_stream_grid((int64_t)N * quads, 256)), dim3(256), 0, stream, x, M, y, N, HW, quads);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -4,7 +4,7 @@
 // (stylegan2ada/torch_utils/ops/upfirdn2d.py:236-240), materialising the intermediate image in HBM.  Its hot users are the
 // augmentation pipe's 2x up- / down-sampling with the 12-tap sym6 low-pass on planar fp32 RGB batches of ~500x500..1000x1000
 // pixels (train_parts/augmentations.py:292,303) and their gradients.  Here a workgroup stages the input window of a 32x64
-// output tile in LDS, runs the row pass LDS -> LDS and the column pass LDS -> registers -> HBM: the image is read once and
+// (16x64 when decimating) output tile in LDS, runs the row pass LDS -> LDS and the column pass LDS -> registers -> HBM: the image is read once and
 // written once (HBM-bound; algorithmic bytes = (numel_in + numel_out) * 4).
 //
 // Planar dense fp32 [M, H, W] planes; up and down in {1, 2} (template parameters, so the polyphase tap strides are constants);
@@ -14,9 +14,13 @@
 
 namespace {
 
-constexpr int TOY = 32, TOX = 64;           // output tile
-constexpr int WIN_H = 80, WIN_W = 160;      // input window capacity (covers down = 2 with up to 16 taps)
-constexpr int MAX_T = 32;
+constexpr int TOX = 64;                     // output tile width (one 256-B row of fp32 per wavefront store)
+constexpr int MAX_T = 16;                   // taps (the window buffers below are sized for it)
+template <int DOWN> struct Tile { static constexpr int TOY = DOWN == 2 ? 16 : 32; };
+template <int UP, int DOWN> struct Win {    // input window of a full tile, +2 for the floor / ceil slack
+    static constexpr int W = ((TOX - 1) * DOWN + MAX_T - 1) / UP + 2;
+    static constexpr int H = ((Tile<DOWN>::TOY - 1) * DOWN + MAX_T - 1) / UP + 2;
+};
 
 struct SepArgs {
     const float* x; const float* f; float* y;
@@ -28,14 +32,17 @@ struct SepArgs {
 static __device__ __forceinline__ int floordiv(int a, int b) { int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 static __device__ __forceinline__ int posmod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
 
+// LDS per workgroup: <2,1> 10 KB, <1,1> 34 KB, <2,2> 22 KB, <1,2> 39 KB -> 4..16 workgroups per CU
 template <int UP, int DOWN>
 __global__ void __launch_bounds__(256) upfirdn2d_sep_kernel(SepArgs p)
 {
-    __shared__ float sf[MAX_T];
-    __shared__ float win[WIN_H * WIN_W];
-    __shared__ float tmp[WIN_H * TOX];
+    constexpr int TOY = Tile<DOWN>::TOY, WW = Win<UP, DOWN>::W, WH = Win<UP, DOWN>::H;
+    constexpr int NK = (MAX_T + UP - 1) / UP;       // taps one output touches (per phase)
+    __shared__ float sf[MAX_T + UP];                // zero-extended, so the unrolled tap loops need no bound check
+    __shared__ float win[WH * WW];
+    __shared__ float tmp[WH * TOX];
     const int tid = threadIdx.x;
-    if (tid < p.T) sf[tid] = p.f[p.flip ? tid : p.T - 1 - tid] * sqrtf(p.gain);
+    if (tid < MAX_T + UP) sf[tid] = tid < p.T ? p.f[p.flip ? tid : p.T - 1 - tid] * sqrtf(p.gain) : 0.0f;
 
     int b = blockIdx.x;
     const int tx = b % p.tiles_x; b /= p.tiles_x;
@@ -48,55 +55,56 @@ __global__ void __launch_bounds__(256) upfirdn2d_sep_kernel(SepArgs p)
     const int uy0 = oy0 * DOWN - p.pady0, uy1 = (oy0 + noy - 1) * DOWN - p.pady0 + p.T - 1;
     const int ix0 = floordiv(ux0 + UP - 1, UP), ix1 = floordiv(ux1, UP);     // ceil(ux0 / UP) .. floor(ux1 / UP)
     const int iy0 = floordiv(uy0 + UP - 1, UP), iy1 = floordiv(uy1, UP);
-    const int ww = ix1 - ix0 + 1, wh = iy1 - iy0 + 1;                        // <= WIN_W, WIN_H (checked by the launcher)
+    const int ww = ix1 - ix0 + 1, wh = iy1 - iy0 + 1;                        // <= WW, WH by construction (T <= MAX_T)
 
     const float* xp = p.x + (int64_t)m * p.IH * p.IW;
-    for (int i = tid; i < wh * ww; i += 256) {
-        const int r = i / ww, c = i - r * ww;
+    for (int i = tid; i < WH * WW; i += 256) {                               // the whole buffer: slack rows / columns read as zeros
+        const int r = i / WW, c = i - r * WW;
         const int iy = iy0 + r, ix = ix0 + c;
-        win[r * WIN_W + c] = (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) ? xp[(int64_t)iy * p.IW + ix] : 0.0f;
+        win[i] = (r < wh && c < ww && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) ? xp[(int64_t)iy * p.IW + ix] : 0.0f;
     }
     __syncthreads();
 
-    // row pass: tmp[r][ox] = sum_k sf[k] * Z[r][ux + k],  Z = zero-inserted window row
-    for (int i = tid; i < wh * TOX; i += 256) {
-        const int r = i / TOX, oxl = i - r * TOX;
-        float acc = 0.0f;
-        if (oxl < nox) {
-            const int base = (ox0 + oxl) * DOWN - p.padx0;
-            const float* row = win + r * WIN_W;
-            for (int k = posmod(-base, UP); k < p.T; k += UP)
-                acc += sf[k] * row[(base + k) / UP - ix0];          // exact division: base + k is a multiple of UP
+    // row pass: tmp[r][ox] = sum_k sf[k] * Z[r][ux + k],  Z = zero-inserted window row; lane = output column
+    {
+        const int oxl = tid & (TOX - 1);
+        const int base = (ox0 + oxl) * DOWN - p.padx0;
+        const int k0 = posmod(-base, UP);
+        const int i0 = (base + k0) / UP - ix0;          // exact division: base + k0 is a multiple of UP; i0 + j < WW + slack
+        float fk[NK];
+#pragma unroll
+        for (int j = 0; j < NK; j++) fk[j] = sf[k0 + j * UP];
+        for (int r = tid / TOX; r < WH; r += 256 / TOX) {      // all rows: the column pass's zero-weight taps may touch the slack rows
+            const float* row = win + r * WW + i0;
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NK; j++) acc += fk[j] * row[min(j, WW - 1 - i0)];
+            tmp[r * TOX + oxl] = acc;
         }
-        tmp[r * TOX + oxl] = acc;
     }
     __syncthreads();
 
     // column pass
     float* yp = p.y + (int64_t)m * p.OH * p.OW;
-    for (int i = tid; i < TOY * TOX; i += 256) {
-        const int oyl = i / TOX, oxl = i - oyl * TOX;
-        if (oyl >= noy || oxl >= nox) continue;
-        const int base = (oy0 + oyl) * DOWN - p.pady0;
-        float acc = 0.0f;
-        for (int k = posmod(-base, UP); k < p.T; k += UP)
-            acc += sf[k] * tmp[((base + k) / UP - iy0) * TOX + oxl];
-        yp[(int64_t)(oy0 + oyl) * p.OW + ox0 + oxl] = acc;
+    {
+        const int oxl = tid & (TOX - 1);
+        for (int oyl = tid / TOX; oyl < noy; oyl += 256 / TOX) {
+            const int base = (oy0 + oyl) * DOWN - p.pady0;
+            const int k0 = posmod(-base, UP);
+            const int r0 = (base + k0) / UP - iy0;
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NK; j++) acc += sf[k0 + j * UP] * tmp[min(r0 + j, WH - 1) * TOX + oxl];
+            if (oxl < nox) yp[(int64_t)(oy0 + oyl) * p.OW + ox0 + oxl] = acc;
+        }
     }
-}
-
-static bool window_fits(int up, int down, int T)
-{
-    // widest window: a full tile; + 2 for the floor / ceil slack
-    const int ww = ((TOX - 1) * down + T - 1) / up + 2, wh = ((TOY - 1) * down + T - 1) / up + 2;
-    return ww <= WIN_W && wh <= WIN_H && T <= MAX_T;
 }
 
 }  // namespace
 
 extern "C" int sbg_upfirdn2d_separable_supported(int up, int down, int taps)
 {
-    return (up == 1 || up == 2) && (down == 1 || down == 2) && taps >= 1 && window_fits(up, down, taps) ? 1 : 0;
+    return (up == 1 || up == 2) && (down == 1 || down == 2) && taps >= 1 && taps <= MAX_T ? 1 : 0;
 }
 
 extern "C" int sbg_upfirdn2d_separable(const float* x, const float* f, float* y, int M, int IH, int IW, int OH, int OW, int taps,
@@ -111,7 +119,8 @@ extern "C" int sbg_upfirdn2d_separable(const float* x, const float* f, float* y,
     SepArgs a;
     a.x = x; a.f = f; a.y = y; a.M = M; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.T = taps;
     a.padx0 = padx0; a.pady0 = pady0; a.flip = flip; a.gain = gain;
-    a.tiles_x = (OW + TOX - 1) / TOX; a.tiles_y = (OH + TOY - 1) / TOY;
+    const int toy = down == 2 ? Tile<2>::TOY : Tile<1>::TOY;
+    a.tiles_x = (OW + TOX - 1) / TOX; a.tiles_y = (OH + toy - 1) / toy;
     const int64_t blocks = (int64_t)M * a.tiles_x * a.tiles_y;
     SBG_CHECK(blocks <= INT32_MAX, "upfirdn2d_separable: too many tiles");
     hipStream_t stream = (hipStream_t)stream_;

@@ -55,48 +55,6 @@ augpipe_specs['bgcfn'] = {**augpipe_specs['bgcf'], **augpipe_specs['noise']}
 augpipe_specs['bgcfnc'] = {**augpipe_specs['bgcfn'], **augpipe_specs['cutout']}
 
 
-# ----------------------------------------------------------------------------------------------------------------
-# host-side homogeneous transforms, batched: every entry is a float or a [N] float32 CPU tensor
-
-def _mat(rows, n):
-    out = torch.zeros([n, len(rows), len(rows[0])], dtype=torch.float32)
-    for i, row in enumerate(rows):
-        for j, v in enumerate(row):
-            out[:, i, j] = v
-    return out
-
-
-def _translate2d(tx, ty, n):
-    return _mat([[1, 0, tx], [0, 1, ty], [0, 0, 1]], n)
-
-
-def _scale2d(sx, sy, n):
-    return _mat([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], n)
-
-
-def _rotate2d(theta, n):
-    c, s = torch.cos(theta), torch.sin(theta)
-    return _mat([[c, torch.sin(-theta), 0], [s, c, 0], [0, 0, 1]], n)
-
-
-def _translate3d(tx, ty, tz, n):
-    return _mat([[1, 0, 0, tx], [0, 1, 0, ty], [0, 0, 1, tz], [0, 0, 0, 1]], n)
-
-
-def _scale3d(sx, sy, sz, n):
-    return _mat([[sx, 0, 0, 0], [0, sy, 0, 0], [0, 0, sz, 0], [0, 0, 0, 1]], n)
-
-
-def _rotate3d(v, theta, n):
-    vx, vy, vz = float(v[0]), float(v[1]), float(v[2])
-    s, c = torch.sin(theta), torch.cos(theta)
-    cc = 1 - c
-    return _mat([[vx * vx * cc + c, vx * vy * cc - vz * s, vx * vz * cc + vy * s, 0],
-                 [vy * vx * cc + vz * s, vy * vy * cc + c, vy * vz * cc - vx * s, 0],
-                 [vz * vx * cc - vy * s, vz * vy * cc + vx * s, vz * vz * cc + c, 0],
-                 [0, 0, 0, 1]], n)
-
-
 class _Filter1d(torch.autograd.Function):
     """per-sample correlation along W (axis 0) or H (axis 1) of [N, C, H, W] fp32 with taps [N, T]; linear, so its
     gradient is the same op with flipped taps and complementary zero padding (any order)."""
@@ -125,6 +83,30 @@ class _Filter1d(torch.autograd.Function):
         axis, pad, flip, t, dtype = ctx.cfg
         dx = _Filter1d.apply(dy, tc, axis, t - 1 - pad, not flip) if ctx.needs_input_grad[0] else None
         return dx, None, None, None, None
+
+
+class _ColorTransform(torch.autograd.Function):
+    """y = M[:, :, :3] @ x + M[:, :, 3:] per sample on planar RGB (one streaming kernel); linear in x, so the gradient is the
+    same op with the transposed 3x3 block (`Mt`, zero offset) -- both matrices come from the host-side sampler."""
+
+    @staticmethod
+    def forward(ctx, x, M, Mt):
+        _lib.require_cuda(x, "AugmentPipe")
+        n, c, h, w = x.shape
+        assert c == 3 and M.shape == (n, 3, 4) and Mt.shape == (n, 3, 4)
+        xc = x.to(torch.float32).contiguous()
+        y = torch.empty_like(xc)
+        Mc = M.contiguous()
+        if y.numel():
+            _lib.check(_lib.load().sbg_color_transform(xc.data_ptr(), Mc.data_ptr(), y.data_ptr(), n, h * w, _lib.stream_ptr(x.device)), "sbg_color_transform")
+        ctx.save_for_backward(M, Mt)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        M, Mt = ctx.saved_tensors
+        zero_off = torch.cat([M[:, :, :3], torch.zeros_like(M[:, :, 3:])], dim=2)
+        return (_ColorTransform.apply(dy, Mt, zero_off) if ctx.needs_input_grad[0] else None), None, None
 
 
 @augmentations.add_to_registry("sg2_ada")
@@ -175,17 +157,31 @@ class AugmentPipe(torch.nn.Module):
     # -- parameters --------------------------------------------------------------------------------------------------
     def sample(self, batch_size, num_channels, height, width, debug_percentile=None, p=None):
         """Draw and compose the parameters of one call on the host.  Order and shapes of the random draws follow the reference's
-        forward (:200-431), so a CPU-seeded call reproduces the reference's CPU run.  Returns a dict of CPU tensors / ints:
-        theta [N,2,3] + margins + up-sampled shape (geometry), color [N,3,4], taps [N,T], sigma [N], cut [N,4]; absent keys =
-        stage disabled."""
+        forward (:200-431) -- torch's CPU generator, so a CPU-seeded call reproduces the reference's CPU run -- and the arithmetic is
+        float32 numpy (a few hundred microseconds per call).  Returns a dict of CPU tensors / ints: theta [N,2,3] + margins +
+        up-sampled shape (geometry), color [N,3,4] (+ color_t for the gradient kernel), taps [N,T], sigma [N], cut [N,4];
+        absent keys = stage disabled."""
         n, W, H = batch_size, width, height
-        p = torch.as_tensor(self._strength() if p is None else p, dtype=torch.float32)
+        f32 = np.float32
+        p = f32(self._strength() if p is None else p)
         dp = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32)
-        rand, randn = torch.rand, torch.randn
+        rand = lambda *s: torch.rand(list(s)).numpy()
+        randn = lambda *s: torch.randn(list(s)).numpy()
+        erf = (lambda std: f32(float(torch.erfinv(dp * 2 - 1)) * std)) if dp is not None else None
+        dpf = None if dp is None else f32(float(dp))
         out = dict()
+        zeros, ones = np.zeros([n], f32), np.ones([n], f32)
 
-        def gate(shape, mult, value, off):
-            return torch.where(rand(shape) < mult * p, value, off)
+        def gate(u, mult, value, off):
+            return np.where(u < f32(mult) * p, value, off).astype(f32)
+
+        def m3(a, b, c, d, e, f):           # [[a, b, c], [d, e, f], [0, 0, 1]] per sample
+            m = np.zeros([n, 3, 3], f32)
+            m[:, 0, 0], m[:, 0, 1], m[:, 0, 2], m[:, 1, 0], m[:, 1, 1], m[:, 1, 2], m[:, 2, 2] = a, b, c, d, e, f, 1
+            return m
+
+        def rot(th):
+            return m3(np.cos(th), np.sin(-th), 0, np.sin(th), np.cos(th), 0)
 
         # pixel blitting + general geometric transforms: G_inv @ pixel_out ==> pixel_in
         G = None
@@ -195,74 +191,77 @@ class AugmentPipe(torch.nn.Module):
             G = m if G is None else G @ m
 
         if self.xflip > 0:
-            i = torch.floor(rand([n]) * 2)
-            i = gate([n], self.xflip, i, torch.zeros_like(i))
+            i = np.floor(rand(n) * 2)
+            i = gate(rand(n), self.xflip, i, zeros)
             if dp is not None:
-                i = torch.full_like(i, torch.floor(dp * 2))
-            chain(_scale2d(1 / (1 - 2 * i), 1, n))
+                i = np.full([n], np.floor(dpf * 2), f32)
+            chain(m3(1 / (1 - 2 * i), 0, 0, 0, 1, 0))
         if self.rotate90 > 0:
-            i = torch.floor(rand([n]) * 4)
-            i = gate([n], self.rotate90, i, torch.zeros_like(i))
+            i = np.floor(rand(n) * 4)
+            i = gate(rand(n), self.rotate90, i, zeros)
             if dp is not None:
-                i = torch.full_like(i, torch.floor(dp * 4))
-            chain(_rotate2d(np.pi / 2 * i, n))
+                i = np.full([n], np.floor(dpf * 4), f32)
+            chain(rot(f32(np.pi / 2) * i))
         if self.xint > 0:
-            t = (rand([n, 2]) * 2 - 1) * self.xint_max
-            t = gate([n, 1], self.xint, t, torch.zeros_like(t))
+            t = (rand(n, 2) * 2 - 1) * f32(self.xint_max)
+            t = gate(rand(n, 1), self.xint, t, np.zeros([n, 2], f32))
             if dp is not None:
-                t = torch.full_like(t, (dp * 2 - 1) * self.xint_max)
-            chain(_translate2d(-torch.round(t[:, 0] * W), -torch.round(t[:, 1] * H), n))
+                t = np.full([n, 2], (dpf * 2 - 1) * f32(self.xint_max), f32)
+            chain(m3(1, 0, -np.round(t[:, 0] * W), 0, 1, -np.round(t[:, 1] * H)))
         if self.scale > 0:
-            s = torch.exp2(randn([n]) * self.scale_std)
-            s = gate([n], self.scale, s, torch.ones_like(s))
+            s = np.exp2(randn(n) * f32(self.scale_std))
+            s = gate(rand(n), self.scale, s, ones)
             if dp is not None:
-                s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.scale_std))
-            chain(_scale2d(1 / s, 1 / s, n))
-        p_rot = 1 - torch.sqrt((1 - self.rotate * p).clamp(0, 1))       # P(pre OR post) = p
+                s = np.full([n], np.exp2(erf(self.scale_std)), f32)
+            chain(m3(1 / s, 0, 0, 0, 1 / s, 0))
+        p_rot = f32(1) - np.sqrt(np.clip(f32(1) - f32(self.rotate) * p, 0, 1))       # P(pre OR post) = p
         if self.rotate > 0:
-            theta = (rand([n]) * 2 - 1) * np.pi * self.rotate_max
-            theta = torch.where(rand([n]) < p_rot, theta, torch.zeros_like(theta))
+            theta = (rand(n) * 2 - 1) * f32(np.pi) * f32(self.rotate_max)
+            theta = np.where(rand(n) < p_rot, theta, zeros).astype(f32)
             if dp is not None:
-                theta = torch.full_like(theta, (dp * 2 - 1) * np.pi * self.rotate_max)
-            chain(_rotate2d(theta, n))      # rotate2d_inv(-theta), before the anisotropic scaling
+                theta = np.full([n], (dpf * 2 - 1) * f32(np.pi) * f32(self.rotate_max), f32)
+            chain(rot(theta))               # rotate2d_inv(-theta), before the anisotropic scaling
         if self.aniso > 0:
-            s = torch.exp2(randn([n]) * self.aniso_std)
-            s = gate([n], self.aniso, s, torch.ones_like(s))
+            s = np.exp2(randn(n) * f32(self.aniso_std))
+            s = gate(rand(n), self.aniso, s, ones)
             if dp is not None:
-                s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.aniso_std))
-            chain(_scale2d(1 / s, 1 / (1 / s), n))
+                s = np.full([n], np.exp2(erf(self.aniso_std)), f32)
+            chain(m3(1 / s, 0, 0, 0, 1 / (1 / s), 0))
         if self.rotate > 0:
-            theta = (rand([n]) * 2 - 1) * np.pi * self.rotate_max
-            theta = torch.where(rand([n]) < p_rot, theta, torch.zeros_like(theta))
+            theta = (rand(n) * 2 - 1) * f32(np.pi) * f32(self.rotate_max)
+            theta = np.where(rand(n) < p_rot, theta, zeros).astype(f32)
             if dp is not None:
-                theta = torch.zeros_like(theta)
-            chain(_rotate2d(theta, n))      # after the anisotropic scaling
+                theta = zeros
+            chain(rot(theta))               # after the anisotropic scaling
         if self.xfrac > 0:
-            t = randn([n, 2]) * self.xfrac_std
-            t = gate([n, 1], self.xfrac, t, torch.zeros_like(t))
+            t = randn(n, 2) * f32(self.xfrac_std)
+            t = gate(rand(n, 1), self.xfrac, t, np.zeros([n, 2], f32))
             if dp is not None:
-                t = torch.full_like(t, torch.erfinv(dp * 2 - 1) * self.xfrac_std)
-            chain(_translate2d(-(t[:, 0] * W), -(t[:, 1] * H), n))
+                t = np.full([n, 2], erf(self.xfrac_std), f32)
+            chain(m3(1, 0, -(t[:, 0] * W), 0, 1, -(t[:, 1] * H)))
 
         if G is not None:
             # padding that keeps every sampled position inside the (reflect-padded) image (:270-285)
             cx, cy = (W - 1) / 2, (H - 1) / 2
-            cp = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], dtype=torch.float32)
-            cp = G @ cp.t()                                                 # [N, xyz, corner]
+            cp = G @ np.asarray([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], f32).T       # [N, xyz, corner]
             hz_pad = self.Hz_geom.shape[0] // 4
-            margin = cp[:, :2, :].permute(1, 0, 2).flatten(1)               # [xy, N * corner]
-            margin = torch.cat([-margin, margin]).max(dim=1).values         # [x0, y0, x1, y1]
-            margin = margin + torch.tensor([hz_pad * 2 - cx, hz_pad * 2 - cy] * 2, dtype=torch.float32)
-            margin = margin.max(torch.zeros(4)).min(torch.tensor([W - 1, H - 1] * 2, dtype=torch.float32))
-            mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32))
+            margin = cp[:, :2, :].transpose(1, 0, 2).reshape(2, -1)             # [xy, N * corner]
+            margin = np.concatenate([-margin, margin]).max(axis=1)              # [x0, y0, x1, y1]
+            margin = margin + np.asarray([hz_pad * 2 - cx, hz_pad * 2 - cy] * 2, f32)
+            margin = np.minimum(np.maximum(margin, 0), np.asarray([W - 1, H - 1] * 2, f32))
+            mx0, my0, mx1, my1 = (int(v) for v in np.ceil(margin).astype(np.int32))
+
+            def one(a, b, c, d, e, f):
+                return np.asarray([[[a, b, c], [d, e, f], [0, 0, 1]]], f32)
             # origin shift of the padding, the 2x up-sampling, and normalisation to the [-1, 1] coordinates of the sampler (:288-300)
-            G = _translate2d((mx0 - mx1) / 2, (my0 - my1) / 2, 1) @ G
-            G = _scale2d(2, 2, 1) @ G @ _scale2d(1 / 2, 1 / 2, 1)
-            G = _translate2d(-0.5, -0.5, 1) @ G @ _translate2d(0.5, 0.5, 1)
+            G = one(1, 0, (mx0 - mx1) / 2, 0, 1, (my0 - my1) / 2) @ G
+            G = one(2, 0, 0, 0, 2, 0) @ G @ one(1 / 2, 0, 0, 0, 1 / 2, 0)
+            G = one(1, 0, -0.5, 0, 1, -0.5) @ G @ one(1, 0, 0.5, 0, 1, 0.5)
             up_h, up_w = (H + my0 + my1) * 2, (W + mx0 + mx1) * 2
             shape = [n, num_channels, (H + hz_pad * 2) * 2, (W + hz_pad * 2) * 2]
-            G = _scale2d(2 / up_w, 2 / up_h, 1) @ G @ _scale2d(1 / (2 / shape[3]), 1 / (2 / shape[2]), 1)
-            out.update(theta=G[:, :2, :].contiguous(), margins=(mx0, mx1, my0, my1), up_shape=(up_h, up_w), grid_shape=shape, hz_pad=hz_pad)
+            G = one(2 / up_w, 0, 0, 0, 2 / up_h, 0) @ G @ one(1 / (2 / shape[3]), 0, 0, 0, 1 / (2 / shape[2]), 0)
+            out.update(theta=torch.from_numpy(np.ascontiguousarray(G[:, :2, :], f32)), margins=(mx0, mx1, my0, my1), up_shape=(up_h, up_w),
+                       grid_shape=shape, hz_pad=hz_pad)
 
         # colour transforms: C @ color_in ==> color_out
         C = None
@@ -271,80 +270,101 @@ class AugmentPipe(torch.nn.Module):
             nonlocal C
             C = m if C is None else m @ C
 
-        v = torch.as_tensor(np.asarray([1, 1, 1, 0]) / np.sqrt(3), dtype=torch.float32)      # luma axis
-        vv = v.ger(v)
-        I4 = torch.eye(4)
+        def m4():
+            m = np.zeros([n, 4, 4], f32)
+            m[:, 0, 0] = m[:, 1, 1] = m[:, 2, 2] = m[:, 3, 3] = 1
+            return m
+
+        v = (np.asarray([1, 1, 1, 0]) / np.sqrt(3)).astype(f32)               # luma axis
+        vv = np.outer(v, v).astype(f32)
+        I4 = np.eye(4, dtype=f32)
         if self.brightness > 0:
-            b = randn([n]) * self.brightness_std
-            b = gate([n], self.brightness, b, torch.zeros_like(b))
+            b = randn(n) * f32(self.brightness_std)
+            b = gate(rand(n), self.brightness, b, zeros)
             if dp is not None:
-                b = torch.full_like(b, torch.erfinv(dp * 2 - 1) * self.brightness_std)
-            cchain(_translate3d(b, b, b, n))
+                b = np.full([n], erf(self.brightness_std), f32)
+            m = m4()
+            m[:, 0, 3] = m[:, 1, 3] = m[:, 2, 3] = b
+            cchain(m)
         if self.contrast > 0:
-            c = torch.exp2(randn([n]) * self.contrast_std)
-            c = gate([n], self.contrast, c, torch.ones_like(c))
+            c = np.exp2(randn(n) * f32(self.contrast_std))
+            c = gate(rand(n), self.contrast, c, ones)
             if dp is not None:
-                c = torch.full_like(c, torch.exp2(torch.erfinv(dp * 2 - 1) * self.contrast_std))
-            cchain(_scale3d(c, c, c, n))
+                c = np.full([n], np.exp2(erf(self.contrast_std)), f32)
+            m = m4()
+            m[:, 0, 0] = m[:, 1, 1] = m[:, 2, 2] = c
+            cchain(m)
         if self.lumaflip > 0:
-            i = torch.floor(rand([n, 1, 1]) * 2)
-            i = gate([n, 1, 1], self.lumaflip, i, torch.zeros_like(i))
+            i = np.floor(rand(n, 1, 1) * 2)
+            i = gate(rand(n, 1, 1), self.lumaflip, i, np.zeros([n, 1, 1], f32))
             if dp is not None:
-                i = torch.full_like(i, torch.floor(dp * 2))
-            cchain(I4 - 2 * vv * i)                                         # Householder reflection
+                i = np.full([n, 1, 1], np.floor(dpf * 2), f32)
+            cchain(I4 - 2 * vv * i)                                             # Householder reflection
         if self.hue > 0 and num_channels > 1:
-            theta = (rand([n]) * 2 - 1) * np.pi * self.hue_max
-            theta = gate([n], self.hue, theta, torch.zeros_like(theta))
+            theta = (rand(n) * 2 - 1) * f32(np.pi) * f32(self.hue_max)
+            theta = gate(rand(n), self.hue, theta, zeros)
             if dp is not None:
-                theta = torch.full_like(theta, (dp * 2 - 1) * np.pi * self.hue_max)
-            cchain(_rotate3d(v, theta, n))
+                theta = np.full([n], (dpf * 2 - 1) * f32(np.pi) * f32(self.hue_max), f32)
+            vx, vy, vz = v[0], v[1], v[2]
+            s, c = np.sin(theta), np.cos(theta)
+            cc = 1 - c
+            m = m4()
+            m[:, 0, 0], m[:, 0, 1], m[:, 0, 2] = vx * vx * cc + c, vx * vy * cc - vz * s, vx * vz * cc + vy * s
+            m[:, 1, 0], m[:, 1, 1], m[:, 1, 2] = vy * vx * cc + vz * s, vy * vy * cc + c, vy * vz * cc - vx * s
+            m[:, 2, 0], m[:, 2, 1], m[:, 2, 2] = vz * vx * cc - vy * s, vz * vy * cc + vx * s, vz * vz * cc + c
+            cchain(m)
         if self.saturation > 0 and num_channels > 1:
-            s = torch.exp2(randn([n, 1, 1]) * self.saturation_std)
-            s = gate([n, 1, 1], self.saturation, s, torch.ones_like(s))
+            s = np.exp2(randn(n, 1, 1) * f32(self.saturation_std))
+            s = gate(rand(n, 1, 1), self.saturation, s, np.ones([n, 1, 1], f32))
             if dp is not None:
-                s = torch.full_like(s, torch.exp2(torch.erfinv(dp * 2 - 1) * self.saturation_std))
+                s = np.full([n, 1, 1], np.exp2(erf(self.saturation_std)), f32)
             cchain(vv + (I4 - vv) * s)
         if C is not None:
+            C = np.broadcast_to(C, [n, 4, 4])
             if num_channels == 3:
-                out['color'] = C[:, :3, :].expand(n, 3, 4).contiguous()
+                out['color'] = torch.from_numpy(np.ascontiguousarray(C[:, :3, :], f32))
+                ct = np.zeros([n, 3, 4], f32)
+                ct[:, :, :3] = C[:, :3, :3].transpose(0, 2, 1)
+                out['color_t'] = torch.from_numpy(ct)
             elif num_channels == 1:
-                Cm = C[:, :3, :].mean(dim=1, keepdims=True).expand(n, 1, 4)
-                out['color'] = torch.cat([Cm[:, :, :3].sum(dim=2, keepdims=True), Cm[:, :, 3:]], dim=2).contiguous()    # [N, 1, 2]: scale, offset
+                Cm = C[:, :3, :].mean(axis=1, keepdims=True)
+                out['color'] = torch.from_numpy(np.concatenate([Cm[:, :, :3].sum(axis=2, keepdims=True), Cm[:, :, 3:]], axis=2).astype(f32))    # [N, 1, 2]: scale, offset
             else:
                 raise ValueError('Image must be RGB (3 channels) or L (1 channel)')
 
         # image-space filter: per-sample gains of the four bands -> one separable filter per sample (:364-381)
         if self.imgfilter > 0:
-            nb = self._fbank_host.shape[0]
+            bank = self._fbank_host.numpy()
+            nb = bank.shape[0]
             assert len(self.imgfilter_bands) == nb
-            expected_power = torch.as_tensor(np.array([10, 1, 1, 1]) / 13, dtype=torch.float32)
-            g = torch.ones([n, nb])
+            expected_power = (np.array([10, 1, 1, 1]) / 13).astype(f32)
+            g = np.ones([n, nb], f32)
             for i, band_strength in enumerate(self.imgfilter_bands):
-                t_i = torch.exp2(randn([n]) * self.imgfilter_std)
-                t_i = torch.where(rand([n]) < self.imgfilter * p * band_strength, t_i, torch.ones_like(t_i))
+                t_i = np.exp2(randn(n) * f32(self.imgfilter_std))
+                t_i = np.where(rand(n) < f32(self.imgfilter) * p * f32(band_strength), t_i, ones).astype(f32)
                 if dp is not None:
-                    t_i = torch.full_like(t_i, torch.exp2(torch.erfinv(dp * 2 - 1) * self.imgfilter_std)) if band_strength > 0 else torch.ones_like(t_i)
-                t = torch.ones([n, nb])
+                    t_i = np.full([n], np.exp2(erf(self.imgfilter_std)), f32) if band_strength > 0 else ones
+                t = np.ones([n, nb], f32)
                 t[:, i] = t_i
-                t = t / (expected_power * t.square()).sum(dim=-1, keepdims=True).sqrt()
+                t = t / np.sqrt((expected_power * np.square(t)).sum(axis=-1, keepdims=True))
                 g = g * t
-            out['taps'] = (g @ self._fbank_host).contiguous()              # [N, T]
+            out['taps'] = torch.from_numpy(np.ascontiguousarray(g @ bank, f32))          # [N, T]
 
         # corruptions
         if self.noise > 0:
-            sigma = randn([n, 1, 1, 1]).abs() * self.noise_std
-            sigma = gate([n, 1, 1, 1], self.noise, sigma, torch.zeros_like(sigma))
+            sigma = np.abs(randn(n, 1, 1, 1)) * f32(self.noise_std)
+            sigma = gate(rand(n, 1, 1, 1), self.noise, sigma, np.zeros([n, 1, 1, 1], f32))
             if dp is not None:
-                sigma = torch.full_like(sigma, torch.erfinv(dp) * self.noise_std)
-            out['sigma'] = sigma.reshape(n)
+                sigma = np.full([n, 1, 1, 1], f32(float(torch.erfinv(dp))) * f32(self.noise_std), f32)
+            out['sigma'] = torch.from_numpy(sigma.reshape(n).astype(f32))
         if self.cutout > 0:
-            size = torch.full([n, 2, 1, 1, 1], self.cutout_size)
-            size = gate([n, 1, 1, 1, 1], self.cutout, size, torch.zeros_like(size))
-            center = rand([n, 2, 1, 1, 1])
+            size = np.full([n, 2, 1, 1, 1], self.cutout_size, f32)
+            size = gate(rand(n, 1, 1, 1, 1), self.cutout, size, np.zeros_like(size))
+            center = rand(n, 2, 1, 1, 1)
             if dp is not None:
-                size = torch.full_like(size, self.cutout_size)
-                center = torch.full_like(center, dp)
-            out['cut'] = torch.cat([center.reshape(n, 2), size.reshape(n, 2)], dim=1)      # cx, cy, sx, sy
+                size = np.full([n, 2, 1, 1, 1], self.cutout_size, f32)
+                center = np.full([n, 2, 1, 1, 1], dpf, f32)
+            out['cut'] = torch.from_numpy(np.concatenate([center.reshape(n, 2), size.reshape(n, 2)], axis=1).astype(f32))      # cx, cy, sx, sy
         return out
 
     # -- image work --------------------------------------------------------------------------------------------------
@@ -356,11 +376,14 @@ class AugmentPipe(torch.nn.Module):
         device = images.device
 
         # one upload for every per-sample parameter
-        names = [k for k in ('theta', 'color', 'taps', 'sigma', 'cut') if k in params]
+        names = [k for k in ('theta', 'color', 'color_t', 'taps', 'sigma', 'cut') if k in params]
         dev = dict()
         if names:
             flat = [params[k].reshape(params[k].shape[0], -1).expand(n, -1).to(torch.float32) for k in names]
-            packed = torch.cat(flat, dim=1).to(device, non_blocking=True)
+            host = torch.cat(flat, dim=1)
+            if device.type == "cuda":       # pinned staging buffer: the upload queues behind the running kernels instead of draining the stream
+                host = host.pin_memory()
+            packed = host.to(device, non_blocking=True)
             off = 0
             for k, f in zip(names, flat):
                 dev[k] = packed[:, off:off + f.shape[1]]
@@ -379,7 +402,11 @@ class AugmentPipe(torch.nn.Module):
         if 'color' in params:
             if ch == 3:
                 Cm = dev['color'].reshape(n, 3, 4)
-                images = torch.baddbmm(Cm[:, :, 3:], Cm[:, :, :3], images.reshape(n, 3, H * W)).reshape(n, 3, H, W)
+                if 'color_t' in dev:
+                    Ct = dev['color_t'].reshape(n, 3, 4)
+                else:       # parameters that did not come from sample(): derive the gradient's matrix on the device
+                    Ct = torch.cat([Cm[:, :, :3].transpose(1, 2), torch.zeros_like(Cm[:, :, 3:])], dim=2)
+                images = _ColorTransform.apply(images, Cm, Ct)
             else:
                 Cm = dev['color'].reshape(n, 1, 2, 1)
                 images = images * Cm[:, :, :1] + Cm[:, :, 1:]
