@@ -221,6 +221,19 @@ int sbg_attention_fwd(const float* theta, const float* phi, const float* g, floa
                       sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * fp32 master weights <-> packed convolution operands.  Replaces the per-call framework chain `w = self.weight * weight_gain`,
+ * `w.to(x.dtype)` (train_parts/generators.py:176-179, discriminators.py:115-118) + layout change, and its autograd mirror.
+ *   sbg_pack_weight:  out[t][a][b] = cast(w[a*sA + b*sB + kh*sKH + kw*sKW] * gain), t = kh*KW + kw, b zero-padded to Bp; `out` is the
+ *                     `w` operand of sbg_conv2d_igemm ([slab][Cout][Cin]); optional w2[a][b] = sum_t (w*gain)^2 (fp32 [A][B], the
+ *                     demodulation's sum over taps, generators.py:71-76).
+ *   sbg_unpack_wgrad: dw[a*sA + b*sB + kh*sKH + kw*sKW] = gain * dwp[t*tap_stride + a*row_stride + b]  (+ 2 gain^2 w[...] dw2[a][b]
+ *                     when dw2 != NULL; dwp may then be NULL): sbg_conv2d_wgrad's fp32 result in the parameter's own layout. */
+int sbg_pack_weight(const float* w, void* out, int out_dtype, int A, int B, int KH, int KW,
+                    int64_t sA, int64_t sB, int64_t sKH, int64_t sKW, int Bp, float gain, float* w2, sbg_stream_t stream);
+int sbg_unpack_wgrad(const float* dwp, int64_t dwp_tap_stride, int64_t dwp_row_stride, float* dw, const float* w, const float* dw2,
+                     int A, int B, int KH, int KW, int64_t sA, int64_t sB, int64_t sKH, int64_t sKW, float gain, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * ADA augmentation pipe, device ops (train_parts/augmentations.py:121-433).
  *
  * grid_sample: bilinear, zero padding, align_corners = False -- the one mode of the reference's
@@ -268,7 +281,7 @@ int sbg_filter1d_batch(const float* x, const float* taps, float* y, int M, int H
  * (or the number pending when out == NULL). */
 enum sbg_kernel_kind {
     SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
-    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13, SBG_K_WEIGHT_PREP = 14
 };
 typedef struct sbg_prof_record {
     int    kind;            /* enum sbg_kernel_kind */

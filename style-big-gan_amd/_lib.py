@@ -90,7 +90,7 @@ class ProfRecord(ctypes.Structure):
 
 
 KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 9: "sn_power", 10: "attention",
-                11: "grid_sample", 12: "filter1d", 13: "color"}
+                11: "grid_sample", 12: "filter1d", 13: "color", 14: "weight_prep"}
 
 _lib = None
 _lock = threading.Lock()
@@ -120,6 +120,10 @@ SYMBOLS = [
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_modconv_bwd_supported", _c.c_int, [_c.c_int]),
     ("sbg_modconv_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
+    ("sbg_pack_weight", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int] + [_c.c_int64] * 4
+     + [_c.c_int, _c.c_float, _c.c_void_p, _c.c_void_p]),
+    ("sbg_unpack_wgrad", _c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 4
+     + [_c.c_int64] * 4 + [_c.c_float, _c.c_void_p]),
     ("sbg_grid_sample2d", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd_overwrites", _c.c_int, [_c.POINTER(GridSampleParams)]),

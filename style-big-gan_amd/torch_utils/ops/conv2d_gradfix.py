@@ -14,6 +14,8 @@ the fp32-input MFMA, which runs at 1/16 of the bf16 rate on gfx950).  ``fp32_mfm
 """
 import contextlib
 
+import weakref
+
 import torch
 
 from ... import _lib
@@ -125,6 +127,57 @@ def _fold_passes(passes, x_cat_dim, w_cat_dim):
     return [(a, b)]
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# fp32 master weights with 16-bit activations ("mixed" launches): the weight operand is cast, scaled and packed by ONE kernel
+# (sbg_pack_weight) instead of `w * gain` -> `.to(dtype)` -> permute/contiguous, and cached while the parameter is unchanged
+# (a parameter is used by several forward / data-gradient launches between two optimizer steps).
+
+_pack_cache = {}
+
+
+def is_mixed(x, w):
+    return w.dtype == torch.float32 and x.dtype in (torch.bfloat16, torch.float16)
+
+
+def _packed_weight(w, rows_dim, dtype, bp, gain, want_w2=False):
+    """w: fp32 [d0, d1, kh, kw] (any strides) -> [kh*kw, A, bp] in `dtype`, rows A = dim `rows_dim`, columns = the other of the first
+    two dims, zero-padded to bp, values cast(w * gain).  Cached for (views of) parameters, keyed on the version counter."""
+    assert w.dtype == torch.float32 and w.ndim == 4 and rows_dim in (0, 1)
+    a_dim, b_dim = rows_dim, 1 - rows_dim
+    A, B, kh, kw = w.shape[a_dim], w.shape[b_dim], w.shape[2], w.shape[3]
+    base = w._base if w._base is not None else w
+    cacheable = isinstance(base, torch.nn.Parameter)
+    key = None
+    if cacheable:
+        key = (base.data_ptr(), w.storage_offset(), tuple(w.shape), tuple(w.stride()), rows_dim, dtype, bp, float(gain), bool(want_w2))
+        hit = _pack_cache.get(key)
+        if hit is not None and hit[0]() is base and hit[1] == base._version:
+            return hit[2], hit[3]
+    out = torch.empty([kh * kw, A, bp], dtype=dtype, device=w.device)
+    w2 = torch.empty([A, B], dtype=torch.float32, device=w.device) if want_w2 else None
+    wd = w.detach()
+    _lib.check(_lib.load().sbg_pack_weight(wd.data_ptr(), out.data_ptr(), _lib.dtype_code(dtype), A, B, kh, kw, wd.stride(a_dim), wd.stride(b_dim),
+                                           wd.stride(2), wd.stride(3), bp, float(gain), _lib.ptr(w2), _lib.stream_ptr(w.device)), "sbg_pack_weight")
+    if cacheable:
+        if len(_pack_cache) > 4096:
+            _pack_cache.clear()
+        _pack_cache[key] = (weakref.ref(base), base._version, out, w2)
+    return out, w2
+
+
+def _unpack_wgrad(out, ca, cb, wshape, wstride, rows_dim, gain, w=None, dw2=None):
+    """out: fp32 [taps, cap, cbp] from _wgrad (or None) -> fp32 gradient with the parameter's shape and strides:
+    dw[.., t] = gain * out[t, a, b] (+ 2 gain^2 w * dw2[a, b])."""
+    dev = out.device if out is not None else w.device
+    dw = torch.empty_strided(wshape, wstride, dtype=torch.float32, device=dev)
+    a_dim, b_dim = rows_dim, 1 - rows_dim
+    assert wshape[a_dim] == ca and wshape[b_dim] == cb
+    _lib.check(_lib.load().sbg_unpack_wgrad(_lib.ptr(out), out.stride(0) if out is not None else 0, out.stride(1) if out is not None else 0,
+                                            dw.data_ptr(), _lib.ptr(w), _lib.ptr(dw2), ca, cb, wshape[2], wshape[3],
+                                            wstride[a_dim], wstride[b_dim], wstride[2], wstride[3], float(gain), _lib.stream_ptr(dev)), "sbg_unpack_wgrad")
+    return dw
+
+
 def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=None, accumulate=False, epi=None):
     """x: [N, Cin, IH, IW] channel-minor 16-bit; wp: packed [slabs, Cout, Cin]; y: [N, Cout, YH, YW] channel-minor.
     Writes y[:, :, y_off[0] + y_step[0]*oy, y_off[1] + y_step[1]*ox] for oy < oh, ox < ow."""
@@ -202,22 +255,27 @@ def epilogue_fusable(x):
     return x.dtype in (torch.bfloat16, torch.float16)
 
 
-def _conv_forward(x, w, stride, padding, epi=None):
-    """y[n,co,oy,ox] = sum x[n,ci,oy*s+kh-p,ox*s+kw-p] w[co,ci,kh,kw] (correlation, like F.conv2d); `epi`: fused Epilogue."""
+def _conv_forward(x, w, stride, padding, epi=None, wgain=1.0):
+    """y[n,co,oy,ox] = sum x[n,ci,oy*s+kh-p,ox*s+kw-p] w[co,ci,kh,kw] (correlation, like F.conv2d); `epi`: fused Epilogue.
+    w may be the fp32 master weight with 16-bit x: the operand is then cast(w * wgain), packed by one kernel."""
     n, cin, ih, iw = x.shape
     cout, cin_w, kh, kw = w.shape
-    assert cin == cin_w and x.dtype == w.dtype
+    mixed = is_mixed(x, w)
+    assert cin == cin_w and (x.dtype == w.dtype or mixed) and (mixed or wgain == 1.0)
     (sh, sw), (ph, pw) = stride, padding
     assert sh == sw, "conv2d: only square strides are implemented"
     oh = (ih + 2 * ph - kh) // sh + 1
     ow = (iw + 2 * pw - kw) // sw + 1
     assert oh >= 1 and ow >= 1
     xp = _pad_channels(x)
-    wpk = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
-    if xp.shape[1] != cin:
-        wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
     taps = [(i - ph, j - pw, i * kw + j) for i in range(kh) for j in range(kw)]
-    passes = _fold_passes(_operand_passes(xp, wpk.contiguous()), 1, 2)
+    if mixed:
+        passes = [(xp, _packed_weight(w, 0, x.dtype, xp.shape[1], wgain)[0])]
+    else:
+        wpk = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
+        if xp.shape[1] != cin:
+            wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
+        passes = _fold_passes(_operand_passes(xp, wpk.contiguous()), 1, 2)
     multi = len(passes) > 1 or len(taps) > _lib.SBG_MAX_TAPS
     y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device, memory_format=torch.channels_last)
     assert epi is None or (not multi)
@@ -230,11 +288,12 @@ def _conv_forward(x, w, stride, padding, epi=None):
     return y.to(x.dtype) if y.dtype != x.dtype else y
 
 
-def _conv_transpose_forward(x, w, stride, padding, output_padding):
+def _conv_transpose_forward(x, w, stride, padding, output_padding, wgain=1.0):
     """y[n,co,iy*s-p+kh, ix*s-p+kw] += x[n,ci,iy,ix] w[ci,co,kh,kw]  (F.conv_transpose2d), computed per output phase."""
     n, cin, ih, iw = x.shape
     cin_w, cout, kh, kw = w.shape
-    assert cin == cin_w and x.dtype == w.dtype
+    mixed = is_mixed(x, w)
+    assert cin == cin_w and (x.dtype == w.dtype or mixed) and (mixed or wgain == 1.0)
     (sh, sw), (ph, pw), (oph, opw) = stride, padding, output_padding
     assert sh == sw, "conv_transpose2d: only square strides are implemented"
     s = sh
@@ -242,10 +301,13 @@ def _conv_transpose_forward(x, w, stride, padding, output_padding):
     ow = (iw - 1) * s - 2 * pw + kw + opw
     assert oh >= 1 and ow >= 1
     xp = _pad_channels(x)
-    wpk = w.permute(2, 3, 1, 0).reshape(kh * kw, cout, cin)
-    if xp.shape[1] != cin:
-        wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
-    passes = _fold_passes(_operand_passes(xp, wpk.contiguous()), 1, 2)
+    if mixed:
+        passes = [(xp, _packed_weight(w, 1, x.dtype, xp.shape[1], wgain)[0])]
+    else:
+        wpk = w.permute(2, 3, 1, 0).reshape(kh * kw, cout, cin)
+        if xp.shape[1] != cin:
+            wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
+        passes = _fold_passes(_operand_passes(xp, wpk.contiguous()), 1, 2)
     # phases: output rows oy = s*o + a use taps kh == (a + p) mod s with input row o + (a + p - kh) / s
     phases = []
     need_zero = False
@@ -324,18 +386,21 @@ def _output_padding_for(transpose, stride, padding, in_hw, out_hw, k_hw):
 
 
 class _Conv(torch.autograd.Function):
-    """cfg = (transpose, stride, padding, output_padding); weight is [Cout, Cin, kh, kw] (plain) or [Cin, Cout, kh, kw] (transpose)."""
+    """cfg = (transpose, stride, padding, output_padding[, wgain]); weight is [Cout, Cin, kh, kw] (plain) or [Cin, Cout, kh, kw]
+    (transpose), in x's dtype -- or the fp32 master weight with 16-bit x ("mixed": the operand is cast(w * wgain), the weight
+    gradient comes back in fp32 in the parameter's layout, already multiplied by wgain)."""
 
     @staticmethod
     def forward(ctx, x, w, cfg):
-        transpose, stride, padding, output_padding = cfg
+        transpose, stride, padding, output_padding = cfg[:4]
+        wgain = cfg[4] if len(cfg) > 4 else 1.0
         _lib.require_cuda(x, "conv2d")
-        if x.dtype != w.dtype:
-            raise RuntimeError(f"conv2d: input ({x.dtype}) and weight ({w.dtype}) must have the same dtype")
+        if x.dtype != w.dtype and not is_mixed(x, w):
+            raise RuntimeError(f"conv2d: input ({x.dtype}) and weight ({w.dtype}) must have the same dtype (or an fp32 weight with 16-bit input)")
         if not transpose:
-            y = _conv_forward(x, w, stride, padding)
+            y = _conv_forward(x, w, stride, padding, wgain=wgain)
         else:
-            y = _conv_transpose_forward(x, w, stride, padding, output_padding)
+            y = _conv_transpose_forward(x, w, stride, padding, output_padding, wgain=wgain)
         ctx.save_for_backward(x, w)
         ctx.cfg = cfg
         return y
@@ -343,21 +408,33 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        transpose, stride, padding, output_padding = ctx.cfg
+        transpose, stride, padding, output_padding = ctx.cfg[:4]
+        wgain = ctx.cfg[4] if len(ctx.cfg) > 4 else 1.0
         dx = dw = None
         if ctx.needs_input_grad[0]:
             op = _output_padding_for(transpose, stride, padding, x.shape[2:], dy.shape[2:], w.shape[2:])
-            dx = _Conv.apply(dy, w, (not transpose, stride, padding, op))
+            if dy.dtype != x.dtype:
+                dy = dy.to(x.dtype)
+            dx = _Conv.apply(dy, w, (not transpose, stride, padding, op, wgain))
             assert dx.shape == x.shape
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            dw = _ConvWgrad.apply(dy, x, ctx.cfg, tuple(w.shape))
+            dw = _ConvWgrad.apply(dy, x, ctx.cfg, tuple(w.shape), wmeta_of(x, w))
         return dx, dw, None
 
 
+def wmeta_of(x, w):
+    """strides of the master weight when the launch is mixed (the weight gradient is then produced in that layout), else None"""
+    return tuple(w.stride()) if is_mixed(x, w) else None
+
+
 class _ConvWgrad(torch.autograd.Function):
+    """(dy, x, cfg, wshape, wmeta) -> dw.  wmeta None: dw in x's dtype (the reference's cuDNN weight-gradient op, conv2d_gradfix.py:140-147);
+    wmeta = strides of the fp32 master weight: dw fp32 in that layout, multiplied by cfg's wgain."""
+
     @staticmethod
-    def forward(ctx, dy, x, cfg, wshape):
-        transpose, stride, padding, _ = cfg
+    def forward(ctx, dy, x, cfg, wshape, wmeta=None):
+        transpose, stride, padding, _ = cfg[:4]
+        wgain = cfg[4] if len(cfg) > 4 else 1.0
         kh, kw = wshape[2], wshape[3]
         taps = [(i - padding[0], j - padding[1]) for i in range(kh) for j in range(kw)]
         assert stride[0] == stride[1]
@@ -367,7 +444,10 @@ class _ConvWgrad(torch.autograd.Function):
             out = _wgrad(dy, x, stride[0], taps)     # [t, Cout, Cin]
         else:
             out = _wgrad(x, dy, stride[0], taps)     # [t, Cin, Cout]
-        dw = out.reshape(kh, kw, wshape[0], wshape[1]).permute(2, 3, 0, 1).to(x.dtype)
+        if wmeta is not None:
+            dw = _unpack_wgrad(out, wshape[0], wshape[1], wshape, wmeta, 0, wgain)
+        else:
+            dw = out.reshape(kh, kw, wshape[0], wshape[1]).permute(2, 3, 0, 1).to(x.dtype)
         ctx.save_for_backward(dy, x)
         ctx.cfg, ctx.wshape = cfg, wshape
         return dw
@@ -375,16 +455,16 @@ class _ConvWgrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ddw):
         dy, x = ctx.saved_tensors
-        transpose, stride, padding, output_padding = ctx.cfg
+        transpose, stride, padding, output_padding = ctx.cfg[:4]
         d_dy = d_x = None
         if ctx.needs_input_grad[0]:
             d_dy = _Conv.apply(x, ddw, ctx.cfg)
             assert d_dy.shape == dy.shape
         if ctx.needs_input_grad[1]:
             op = _output_padding_for(transpose, stride, padding, x.shape[2:], dy.shape[2:], ctx.wshape[2:])
-            d_x = _Conv.apply(dy, ddw, (not transpose, stride, padding, op))
+            d_x = _Conv.apply(dy, ddw, (not transpose, stride, padding, op) + tuple(ctx.cfg[4:]))
             assert d_x.shape == x.shape
-        return d_dy, d_x, None, None
+        return d_dy, d_x, None, None, None
 
 
 def _grouped(fn, input, weight, groups, transpose):
@@ -404,11 +484,13 @@ def _add_bias(y, bias):
     return bias_act.bias_act(y, bias.to(y.dtype))
 
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    """Same contract as torch.nn.functional.conv2d / the reference's conv2d (conv2d_gradfix.py:35), HIP kernels inside."""
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, wgain=1.0):
+    """Same contract as torch.nn.functional.conv2d / the reference's conv2d (conv2d_gradfix.py:35), HIP kernels inside.
+    Extension: `weight` may be the fp32 master parameter with a 16-bit input; the operand is then cast(weight * wgain)."""
     _lib.require_cuda(input, "conv2d")
     assert _pair(dilation) == (1, 1), "conv2d: dilation is not implemented"
-    cfg = (False, _pair(stride), _pair(padding), (0, 0))
+    cfg = (False, _pair(stride), _pair(padding), (0, 0), float(wgain))
+    assert groups == 1 or not is_mixed(input, weight)
     assert all(p >= 0 for p in cfg[2]) and all(s >= 1 for s in cfg[1])
     if groups == 1:
         y = _Conv.apply(input, weight, cfg)
@@ -417,11 +499,12 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     return _add_bias(y, bias)
 
 
-def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, wgain=1.0):
     """Same contract as torch.nn.functional.conv_transpose2d / the reference's conv_transpose2d (conv2d_gradfix.py:40)."""
     _lib.require_cuda(input, "conv_transpose2d")
     assert _pair(dilation) == (1, 1), "conv_transpose2d: dilation is not implemented"
-    cfg = (True, _pair(stride), _pair(padding), _pair(output_padding))
+    cfg = (True, _pair(stride), _pair(padding), _pair(output_padding), float(wgain))
+    assert groups == 1 or not is_mixed(input, weight)
     assert all(0 <= cfg[3][i] < max(cfg[1][i], 1) or cfg[3][i] == 0 for i in range(2))
     if groups == 1:
         y = _Conv.apply(input, weight, cfg)

@@ -14,16 +14,16 @@ from . import upfirdn2d
 from .upfirdn2d import _get_filter_size, _parse_padding
 
 
-def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, tail=None):
+def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True, tail=None, wgain=1.0):
     """plain / transposed convolution; flips the taps when a true convolution is requested.
     `tail` = dict(b, act, alpha, gain, clamp): the bias_act that follows, fused into the kernel epilogue when possible."""
     if not flip_weight:
         w = w.flip([2, 3])
     if tail is not None and not transpose and conv_bias_act.fusable(x, w, tail["act"], groups):
         return conv_bias_act.conv2d_bias_act(x, w, tail["b"], stride=stride, padding=padding, act=tail["act"], alpha=tail["alpha"],
-                                             gain=tail["gain"], clamp=tail["clamp"])
+                                             gain=tail["gain"], clamp=tail["clamp"], wgain=wgain)
     fn = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
-    y = fn(x, w, stride=stride, padding=padding, groups=groups)
+    y = fn(x, w, stride=stride, padding=padding, groups=groups, wgain=wgain)
     return _tail(y, tail)
 
 
@@ -36,17 +36,21 @@ def _tail(y, tail):
     return bias_act.bias_act(y, b, act=tail["act"], alpha=tail["alpha"], gain=tail["gain"], clamp=tail["clamp"])
 
 
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, bias_act_tail=None, fir_tail=None):
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, bias_act_tail=None, fir_tail=None,
+                    wgain=1.0):
     """x: [N, Cin, H, W]; w: [Cout, Cin // groups, kh, kw] (same dtype); f: filter from upfirdn2d.setup_filter().
     `padding` is relative to the upsampled image.  Returns [N, Cout, H * up // down (+ padding), ...].
     `bias_act_tail` (extension): dict(b, act, alpha, gain, clamp) -- apply that bias_act to the result, fused into the
     convolution kernel when the convolution is the last stage.
     `fir_tail` (extension, up-sampling branch): dict(dcoefs, noise, b, act, alpha, gain, clamp) -- the demodulation + noise + bias_act
     of a synthesis layer, fused into the low-pass kernel that ends the branch (first order only; the caller checks
-    upfirdn2d.fir_tail_supported on the result of fir_tail_probe)."""
+    upfirdn2d.fir_tail_supported on the result of fir_tail_probe).
+    `wgain` (extension): with 16-bit x, `w` may be the layer's fp32 parameter; the convolution operand is then cast(w * wgain), prepared
+    (and cached) by one kernel, and the weight gradient arrives in fp32 in the parameter's layout."""
     tail = bias_act_tail
     assert isinstance(x, torch.Tensor) and x.ndim == 4
-    assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
+    assert isinstance(w, torch.Tensor) and w.ndim == 4 and (w.dtype == x.dtype or conv2d_gradfix.is_mixed(x, w))
+    assert wgain == 1.0 or conv2d_gradfix.is_mixed(x, w)
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
     assert isinstance(up, int) and up >= 1 and isinstance(down, int) and down >= 1
     assert isinstance(groups, int) and groups >= 1
@@ -66,15 +70,15 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
 
     if pointwise and down > 1 and up == 1:          # resample on the cheap side of a 1x1 conv: first shrink ...
         x = upfirdn2d.upfirdn2d(x, f, down=down, padding=pad4, flip_filter=flip_filter)
-        return _conv(x, w, groups=groups, flip_weight=flip_weight, tail=tail)
+        return _conv(x, w, groups=groups, flip_weight=flip_weight, tail=tail, wgain=wgain)
 
     if pointwise and up > 1 and down == 1:          # ... or convolve first, then grow
-        x = _conv(x, w, groups=groups, flip_weight=flip_weight)
+        x = _conv(x, w, groups=groups, flip_weight=flip_weight, wgain=wgain)
         return _tail(upfirdn2d.upfirdn2d(x, f, up=up, padding=pad4, gain=up ** 2, flip_filter=flip_filter), tail)
 
     if down > 1 and up == 1:                        # low-pass at full resolution, then a strided convolution
         x = upfirdn2d.upfirdn2d(x, f, padding=pad4, flip_filter=flip_filter)
-        return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight, tail=tail)
+        return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight, tail=tail, wgain=wgain)
 
     if up > 1:                                      # transposed strided convolution, then low-pass (and optional decimation)
         if groups == 1:
@@ -85,7 +89,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         py0 -= kh - 1; py1 -= kh - up
         pxt = max(min(-px0, -px1), 0)
         pyt = max(min(-py0, -py1), 0)
-        x = _conv(x, wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
+        x = _conv(x, wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight), wgain=wgain)
         fpad = [px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt]
         if fir_tail is not None and down == 1 and upfirdn2d.fir_tail_supported(x, f, fpad, flip_filter):
             return upfirdn2d.fir_bias_act(x, f, fpad, up ** 2, fir_tail["dcoefs"], fir_tail["noise"], fir_tail["b"], act=fir_tail["act"],
@@ -101,11 +105,11 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         return _tail(x, tail)
 
     if px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:     # plain convolution with symmetric padding
-        return _conv(x, w, padding=[py0, px0], groups=groups, flip_weight=flip_weight, tail=tail)
+        return _conv(x, w, padding=[py0, px0], groups=groups, flip_weight=flip_weight, tail=tail, wgain=wgain)
 
     # generic composition: pad/crop with an identity FIR, convolve, decimate
     x = upfirdn2d.upfirdn2d(x, (f if up > 1 else None), up=up, padding=pad4, gain=up ** 2, flip_filter=flip_filter)
-    x = _conv(x, w, groups=groups, flip_weight=flip_weight)
+    x = _conv(x, w, groups=groups, flip_weight=flip_weight, wgain=wgain)
     if down > 1:
         x = upfirdn2d.upfirdn2d(x, f, down=down, flip_filter=flip_filter)
     return _tail(x, tail)

@@ -83,12 +83,12 @@ class _ModConvBiasAct(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 dstyles = _mod._dot_hw_launch(dxs, x).to(styles.dtype).reshape(styles.shape)
         if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
-            dw = _cg._ConvWgrad.apply(d2, xs, ccfg, tuple(w.shape))
+            dw = _cg._ConvWgrad.apply(d2, xs, ccfg, tuple(w.shape), _cg.wmeta_of(xs, w))
         return dx, dw, dstyles, ddcoefs, dnoise, db, None
 
 
 def modconv_bias_act(x, weight, styles, dcoefs, noise, bias, padding, act="lrelu", alpha=None, gain=None, clamp=None):
-    """Fused SynthesisLayer body (up = 1): x [N, Cin, H, W] 16-bit, weight [Cout, Cin, k, k] same dtype, styles [N, Cin],
+    """Fused SynthesisLayer body (up = 1): x [N, Cin, H, W] 16-bit, weight [Cout, Cin, k, k] same dtype or the fp32 parameter, styles [N, Cin],
     dcoefs [N, Cout] (demodulation coefficients, differentiable), noise None / [N, 1, H, W] / [H, W], bias [Cout]."""
     spec = _ba.activation_funcs[act]
     cfg = (int(padding), act, float(alpha if alpha is not None else spec.def_alpha), float(gain if gain is not None else spec.def_gain),

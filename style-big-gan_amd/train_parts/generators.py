@@ -153,11 +153,15 @@ class Conv2dLayer(torch.nn.Module):
                 self.bias = None
 
     def forward(self, x, gain=1):
-        w = self.weight * self.weight_gain
         b = self.bias               # fp32 as stored: the fused epilogue takes fp32, the unfused tail casts
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         # conv2d_resample + bias_act (reference :179-184); the bias_act rides in the convolution kernel's epilogue when it can
         tail = dict(b=b, act=self.activation, alpha=None, gain=self.act_gain * gain, clamp=clamp)
+        if conv2d_gradfix.is_mixed(x, self.weight) and x.device.type == 'cuda':
+            # 16-bit block: hand the fp32 parameter over; `w * weight_gain`, the cast and the operand layout are one (cached) kernel
+            return conv2d_resample.conv2d_resample(x=x, w=self.weight, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
+                                                   flip_weight=(self.up == 1), bias_act_tail=tail, wgain=self.weight_gain)
+        w = self.weight * self.weight_gain
         return conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
                                                padding=self.padding, flip_weight=(self.up == 1), bias_act_tail=tail)
 
@@ -270,10 +274,10 @@ class SynthesisLayer(torch.nn.Module):
                 spec = bias_act.activation_funcs[self.activation]
                 epi = conv2d_gradfix.Epilogue(oscale=dcoefs, noise=noise, bias=self.bias, act=self.activation, alpha=spec.def_alpha,
                                               gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1))
-                return conv2d_gradfix._conv_forward(xs, self.weight.to(x.dtype), (1, 1), (self.padding, self.padding), epi=epi)
+                return conv2d_gradfix._conv_forward(xs, self.weight, (1, 1), (self.padding, self.padding), epi=epi)
         if modconv.usable(x, self.weight, self.activation, self.up):
             # training pass, first order: same fused epilogue, plus a one-pass backward head (torch_utils/ops/modconv.py)
-            return modconv.modconv_bias_act(x, self.weight.to(x.dtype), styles, demod_coefficients(self.weight, styles), noise, self.bias,
+            return modconv.modconv_bias_act(x, self.weight, styles, demod_coefficients(self.weight, styles), noise, self.bias,
                                             padding=self.padding, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
         if (self.up == 2 and modconv.enabled and x.device.type == 'cuda' and x.dtype == torch.bfloat16
                 and self.activation in ('linear', 'relu', 'lrelu')):
@@ -282,7 +286,7 @@ class SynthesisLayer(torch.nn.Module):
             spec = bias_act.activation_funcs[self.activation]
             tail = dict(dcoefs=demod_coefficients(self.weight, styles), noise=noise, b=self.bias, act=self.activation, alpha=spec.def_alpha,
                         gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1))
-            return conv2d_resample.conv2d_resample(x=modulate.scale_nc(x, styles), w=self.weight.to(x.dtype), f=self.resample_filter, up=2,
+            return conv2d_resample.conv2d_resample(x=modulate.scale_nc(x, styles), w=self.weight, f=self.resample_filter, up=2,
                                                    padding=self.padding, flip_weight=False, fir_tail=tail)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
@@ -301,9 +305,9 @@ class ToRGBLayer(torch.nn.Module):
 
     def forward(self, x, w, fused_modconv=True):
         styles = self.affine(w) * self.weight_gain
-        wt = self.weight.to(x.dtype)
-        if conv_bias_act.fusable(x, wt, 'linear'):      # modulation pass, then 1x1 convolution with bias + clamp in its epilogue
+        if conv_bias_act.fusable(x, self.weight, 'linear'):      # modulation pass, then 1x1 convolution with bias + clamp in its epilogue
             xs = modulate.scale_nc(x, styles)
+            wt = self.weight if conv2d_gradfix.is_mixed(x, self.weight) else self.weight.to(x.dtype)
             return conv_bias_act.conv2d_bias_act(xs, wt, self.bias, act='linear', clamp=self.conv_clamp)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
