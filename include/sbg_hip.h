@@ -233,6 +233,13 @@ int sbg_pack_weight(const float* w, void* out, int out_dtype, int A, int B, int 
 int sbg_unpack_wgrad(const float* dwp, int64_t dwp_tap_stride, int64_t dwp_row_stride, float* dw, const float* w, const float* dw2,
                      int A, int B, int KH, int KW, int64_t sA, int64_t sB, int64_t sKH, int64_t sKW, float gain, sbg_stream_t stream);
 
+/* Demodulation coefficients of a modulated convolution from the tap-summed squared weights w2 [O][I] (sbg_pack_weight's by-product):
+ *   dcoefs[n, o] = rsqrt(sum_i styles[n, i]^2 * w2[o, i] + eps)        (train_parts/generators.py:71-76: `(w * s).square().sum([2,3,4]) + 1e-8).rsqrt()`
+ * and the first-order gradient: g = d loss / d dcoefs -> dstyles [N][I], dw2 [O][I] (either may be NULL).  All fp32, dense. */
+int sbg_demod_coefs(const float* styles, const float* w2, float* dcoefs, int N, int O, int I, float eps, sbg_stream_t stream);
+int sbg_demod_coefs_bwd(const float* g, const float* dcoefs, const float* styles, const float* w2, float* dstyles, float* dw2,
+                        int N, int O, int I, sbg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * ADA augmentation pipe, device ops (train_parts/augmentations.py:121-433).
  *

@@ -124,6 +124,8 @@ SYMBOLS = [
      + [_c.c_int, _c.c_float, _c.c_void_p, _c.c_void_p]),
     ("sbg_unpack_wgrad", _c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 4
      + [_c.c_int64] * 4 + [_c.c_float, _c.c_void_p]),
+    ("sbg_demod_coefs", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 3 + [_c.c_float, _c.c_void_p]),
+    ("sbg_demod_coefs_bwd", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int] * 3 + [_c.c_void_p]),
     ("sbg_grid_sample2d", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd_overwrites", _c.c_int, [_c.POINTER(GridSampleParams)]),

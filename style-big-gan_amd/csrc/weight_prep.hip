@@ -105,3 +105,103 @@ extern "C" int sbg_unpack_wgrad(const float* dwp, int64_t dwp_tap_stride, int64_
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Demodulation coefficients from the tap-summed squared weights (generators.py:71-76 without the [N, O, I, k, k] tensor):
+//   d[n, o] = rsqrt(sum_i s[n, i]^2 * w2[o, i] + eps)
+// and their first-order gradient: with q[n, o] = -0.5 * g[n, o] * d[n, o]^3,
+//   ds[n, i] = 2 s[n, i] * sum_o q[n, o] * w2[o, i],      dw2[o, i] = sum_n q[n, o] * s[n, i]^2.
+namespace {
+
+// one wavefront per (n, o): lanes stride over i (coalesced w2 row), shuffle reduction
+__global__ void __launch_bounds__(256) demod_coefs_kernel(const float* __restrict__ s, const float* __restrict__ w2, float* __restrict__ d,
+                                                          int N, int O, int I, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (int64_t)N * O) return;
+    const int n = (int)(pair / O), o = (int)(pair % O);
+    const float* sr = s + (int64_t)n * I;
+    const float* wr = w2 + (int64_t)o * I;
+    float acc = 0.0f;
+    for (int i = lane; i < I; i += 64) { const float sv = sr[i]; acc += sv * sv * wr[i]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) d[pair] = rsqrtf(acc + eps);
+}
+
+// ds: block = (n, 64 consecutive i); the four wavefronts split the sum over o (stride 4, eight loads in flight each), LDS combine
+__global__ void __launch_bounds__(256) demod_bwd_styles_kernel(const float* __restrict__ g, const float* __restrict__ d, const float* __restrict__ s,
+                                                               const float* __restrict__ w2, float* __restrict__ ds, int N, int O, int I)
+{
+    extern __shared__ float q[];            // [O] then 4 x 64 partial sums
+    float* part = q + O;
+    const int chunks = (I + 63) / 64;
+    const int n = blockIdx.x / chunks, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = (blockIdx.x % chunks) * 64 + lane;
+    for (int o = threadIdx.x; o < O; o += 256) { const float dv = d[(int64_t)n * O + o]; q[o] = -0.5f * g[(int64_t)n * O + o] * dv * dv * dv; }
+    __syncthreads();
+    float acc = 0.0f;
+    if (i < I) {
+        int o = wave;
+        for (; o + 28 < O; o += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = w2[(int64_t)(o + 4 * u) * I + i];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += q[o + 4 * u] * v[u];
+        }
+        for (; o < O; o += 4) acc += q[o] * w2[(int64_t)o * I + i];
+    }
+    part[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && i < I)
+        ds[(int64_t)n * I + i] = 2.0f * s[(int64_t)n * I + i] * (part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]);
+}
+
+// dw2: one lane per (o, i); the N-term sum reads s^2 coalesced and q broadcast
+__global__ void __launch_bounds__(256) demod_bwd_w2_kernel(const float* __restrict__ g, const float* __restrict__ d, const float* __restrict__ s,
+                                                           float* __restrict__ dw2, int N, int O, int I)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)O * I) return;
+    const int o = (int)(idx / I), i = (int)(idx % I);
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int n = 0; n < N; n++) {
+        const float dv = d[(int64_t)n * O + o], sv = s[(int64_t)n * I + i];
+        acc += (-0.5f * g[(int64_t)n * O + o] * dv * dv * dv) * sv * sv;
+    }
+    dw2[idx] = acc;
+}
+
+}  // namespace
+
+extern "C" int sbg_demod_coefs(const float* styles, const float* w2, float* dcoefs, int N, int O, int I, float eps, sbg_stream_t stream_)
+{
+    SBG_CHECK(styles && w2 && dcoefs && N >= 1 && O >= 1 && I >= 1, "demod_coefs: bad arguments");
+    hipStream_t stream = (hipStream_t)stream_;
+    SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 2.0 * N * O * (double)I, 4.0 * ((double)N * I + (double)O * I + (double)N * O), {N, O, I, 2, 0, 0, 0});
+    hipLaunchKernelGGL(demod_coefs_kernel, dim3((unsigned)(((int64_t)N * O + 3) / 4)), dim3(256), 0, stream, styles, w2, dcoefs, N, O, I, eps);
+    SBG_HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sbg_demod_coefs_bwd(const float* g, const float* dcoefs, const float* styles, const float* w2, float* dstyles, float* dw2,
+                                   int N, int O, int I, sbg_stream_t stream_)
+{
+    SBG_CHECK(g && dcoefs && styles && w2 && (dstyles || dw2) && N >= 1 && O >= 1 && I >= 1, "demod_coefs_bwd: bad arguments");
+    SBG_CHECK((O + 256) * sizeof(float) <= 64 * 1024, "demod_coefs_bwd: too many output channels");
+    hipStream_t stream = (hipStream_t)stream_;
+    SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 4.0 * N * O * (double)I, 4.0 * (2.0 * N * I + 2.0 * O * I + 2.0 * N * O), {N, O, I, 3, 0, 0, 0});
+    if (dstyles) {
+        const int chunks = (I + 63) / 64;
+        hipLaunchKernelGGL(demod_bwd_styles_kernel, dim3((unsigned)(N * chunks)), dim3(256), (O + 256) * sizeof(float), stream, g, dcoefs, styles, w2, dstyles, N, O, I);
+        SBG_HIP_LAUNCH_CHECK();
+    }
+    if (dw2) {
+        hipLaunchKernelGGL(demod_bwd_w2_kernel, dim3((unsigned)(((int64_t)O * I + 255) / 256)), dim3(256), 0, stream, g, dcoefs, styles, dw2, N, O, I);
+        SBG_HIP_LAUNCH_CHECK();
+    }
+    return 0;
+}

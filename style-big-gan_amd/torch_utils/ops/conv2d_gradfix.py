@@ -139,9 +139,10 @@ def is_mixed(x, w):
     return w.dtype == torch.float32 and x.dtype in (torch.bfloat16, torch.float16)
 
 
-def _packed_weight(w, rows_dim, dtype, bp, gain, want_w2=False):
+def _packed_weight(w, rows_dim, dtype, bp, gain):
     """w: fp32 [d0, d1, kh, kw] (any strides) -> [kh*kw, A, bp] in `dtype`, rows A = dim `rows_dim`, columns = the other of the first
-    two dims, zero-padded to bp, values cast(w * gain).  Cached for (views of) parameters, keyed on the version counter."""
+    two dims, zero-padded to bp, values cast(w * gain); also w2 [A, B] = sum over taps of (w * gain)^2 for rows_dim == 0 (the
+    demodulation's reduction, free in the same pass).  Cached for (views of) parameters, keyed on the version counter."""
     assert w.dtype == torch.float32 and w.ndim == 4 and rows_dim in (0, 1)
     a_dim, b_dim = rows_dim, 1 - rows_dim
     A, B, kh, kw = w.shape[a_dim], w.shape[b_dim], w.shape[2], w.shape[3]
@@ -149,18 +150,21 @@ def _packed_weight(w, rows_dim, dtype, bp, gain, want_w2=False):
     cacheable = isinstance(base, torch.nn.Parameter)
     key = None
     if cacheable:
-        key = (base.data_ptr(), w.storage_offset(), tuple(w.shape), tuple(w.stride()), rows_dim, dtype, bp, float(gain), bool(want_w2))
+        key = (base.data_ptr(), w.storage_offset(), tuple(w.shape), tuple(w.stride()), rows_dim, dtype, bp, float(gain))
         hit = _pack_cache.get(key)
         if hit is not None and hit[0]() is base and hit[1] == base._version:
             return hit[2], hit[3]
     out = torch.empty([kh * kw, A, bp], dtype=dtype, device=w.device)
-    w2 = torch.empty([A, B], dtype=torch.float32, device=w.device) if want_w2 else None
+    w2 = torch.empty([A, B], dtype=torch.float32, device=w.device) if rows_dim == 0 else None
     wd = w.detach()
     _lib.check(_lib.load().sbg_pack_weight(wd.data_ptr(), out.data_ptr(), _lib.dtype_code(dtype), A, B, kh, kw, wd.stride(a_dim), wd.stride(b_dim),
                                            wd.stride(2), wd.stride(3), bp, float(gain), _lib.ptr(w2), _lib.stream_ptr(w.device)), "sbg_pack_weight")
     if cacheable:
-        if len(_pack_cache) > 4096:
-            _pack_cache.clear()
+        if len(_pack_cache) > 256:          # drop the operands of parameters that no longer exist
+            for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
+                del _pack_cache[k]
+            if len(_pack_cache) > 2048:
+                _pack_cache.clear()
         _pack_cache[key] = (weakref.ref(base), base._version, out, w2)
     return out, w2
 

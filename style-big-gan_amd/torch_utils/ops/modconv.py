@@ -87,6 +87,47 @@ class _ModConvBiasAct(torch.autograd.Function):
         return dx, dw, dstyles, ddcoefs, dnoise, db, None
 
 
+class _DemodCoefs(torch.autograd.Function):
+    """dcoefs[n, o] = rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[n,i])^2 + 1e-8) from the fp32 parameter (generators.py:71-76): the sum over
+    taps comes out of the (cached) operand-packing pass, the rest is one small kernel; backward = two small kernels + the
+    gradient's `2 w dw2` written in the parameter's layout.  First order only, like the fused layers that consume it."""
+
+    @staticmethod
+    def forward(ctx, weight, styles, act_dtype):
+        assert weight.dtype == torch.float32 and weight.ndim == 4
+        o, i = weight.shape[0], weight.shape[1]
+        n = styles.shape[0]
+        _, w2 = _cg._packed_weight(weight, 0, act_dtype, (i + 7) // 8 * 8, 1.0)
+        s32 = styles.detach().to(torch.float32).contiguous()
+        d = torch.empty([n, o], dtype=torch.float32, device=weight.device)
+        _lib.check(_lib.load().sbg_demod_coefs(s32.data_ptr(), w2.data_ptr(), d.data_ptr(), n, o, i, 1e-8, _lib.stream_ptr(weight.device)), "sbg_demod_coefs")
+        ctx.save_for_backward(weight, s32, w2, d)
+        ctx.s_dtype = styles.dtype
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, s32, w2, d = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            raise RuntimeError("demod_coefs: first-order only; set torch_utils.ops.modconv.enabled = False for double backward")
+        n, o = d.shape
+        i = s32.shape[1]
+        g = g.to(torch.float32).contiguous()
+        ds = torch.empty_like(s32) if ctx.needs_input_grad[1] else None
+        dw2 = torch.empty_like(w2) if ctx.needs_input_grad[0] else None
+        _lib.check(_lib.load().sbg_demod_coefs_bwd(g.data_ptr(), d.data_ptr(), s32.data_ptr(), w2.data_ptr(), _lib.ptr(ds), _lib.ptr(dw2), n, o, i,
+                                                   _lib.stream_ptr(g.device)), "sbg_demod_coefs_bwd")
+        dw = None
+        if dw2 is not None:
+            dw = _cg._unpack_wgrad(None, o, i, tuple(weight.shape), tuple(weight.stride()), 0, 1.0, w=weight.detach(), dw2=dw2)
+        return dw, (ds.to(ctx.s_dtype) if ds is not None else None), None
+
+
+def demod_coefs(weight, styles, act_dtype):
+    """fused demodulation coefficients (see _DemodCoefs); weight: the layer's fp32 parameter, act_dtype: dtype of the layer's activations"""
+    return _DemodCoefs.apply(weight, styles, act_dtype)
+
+
 def modconv_bias_act(x, weight, styles, dcoefs, noise, bias, padding, act="lrelu", alpha=None, gain=None, clamp=None):
     """Fused SynthesisLayer body (up = 1): x [N, Cin, H, W] 16-bit, weight [Cout, Cin, k, k] same dtype or the fp32 parameter, styles [N, Cin],
     dcoefs [N, Cout] (demodulation coefficients, differentiable), noise None / [N, 1, H, W] / [H, W], bias [Cout]."""

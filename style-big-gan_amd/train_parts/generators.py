@@ -48,8 +48,12 @@ def normalize_2nd_moment(x, dim=1, eps=1e-8):
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
 
-def demod_coefficients(weight, styles):
-    """dcoefs[n, o] = rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[n,i])^2 + 1e-8), as a [N, I] x [I, O] product (fp32)."""
+def demod_coefficients(weight, styles, act_dtype=None):
+    """dcoefs[n, o] = rsqrt(sum_{i,kh,kw} (w[o,i,kh,kw] * s[n,i])^2 + 1e-8), as a [N, I] x [I, O] product (fp32).
+    `act_dtype` (16-bit, first-order passes of the fused layers): the HIP path that shares the packed-weight pass (ops/modconv.py)."""
+    if (act_dtype in (torch.bfloat16, torch.float16) and modconv.enabled and weight.dtype == torch.float32 and weight.device.type == 'cuda'
+            and styles.device.type == 'cuda'):
+        return modconv.demod_coefs(weight, styles, act_dtype)
     w2 = weight.to(torch.float32).square().sum(dim=[2, 3])            # [O, I]
     return (styles.to(torch.float32).square() @ w2.t() + 1e-8).rsqrt()   # [N, O]
 
@@ -269,7 +273,7 @@ class SynthesisLayer(torch.nn.Module):
             # inference-only pass (e.g. the generator inside the discriminator phases): demodulation, noise, bias, activation,
             # gain and clamp all ride in the convolution kernel's epilogue -- one read of x*s, one write of y
             with torch.no_grad():
-                dcoefs = demod_coefficients(self.weight, styles)
+                dcoefs = demod_coefficients(self.weight, styles, x.dtype)
                 xs = modulate.scale_nc(x, styles)
                 spec = bias_act.activation_funcs[self.activation]
                 epi = conv2d_gradfix.Epilogue(oscale=dcoefs, noise=noise, bias=self.bias, act=self.activation, alpha=spec.def_alpha,
@@ -277,14 +281,14 @@ class SynthesisLayer(torch.nn.Module):
                 return conv2d_gradfix._conv_forward(xs, self.weight, (1, 1), (self.padding, self.padding), epi=epi)
         if modconv.usable(x, self.weight, self.activation, self.up):
             # training pass, first order: same fused epilogue, plus a one-pass backward head (torch_utils/ops/modconv.py)
-            return modconv.modconv_bias_act(x, self.weight, styles, demod_coefficients(self.weight, styles), noise, self.bias,
+            return modconv.modconv_bias_act(x, self.weight, styles, demod_coefficients(self.weight, styles, x.dtype), noise, self.bias,
                                             padding=self.padding, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
         if (self.up == 2 and modconv.enabled and x.device.type == 'cuda' and x.dtype == torch.bfloat16
                 and self.activation in ('linear', 'relu', 'lrelu')):
             # up-sampling layer, first-order training pass: x * s -> transposed convolution (one multi-phase launch) -> low-pass whose kernel
             # epilogue carries demodulation, noise, bias, activation, gain and clamp (falls back to the composition inside conv2d_resample)
             spec = bias_act.activation_funcs[self.activation]
-            tail = dict(dcoefs=demod_coefficients(self.weight, styles), noise=noise, b=self.bias, act=self.activation, alpha=spec.def_alpha,
+            tail = dict(dcoefs=demod_coefficients(self.weight, styles, x.dtype), noise=noise, b=self.bias, act=self.activation, alpha=spec.def_alpha,
                         gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1))
             return conv2d_resample.conv2d_resample(x=modulate.scale_nc(x, styles), w=self.weight, f=self.resample_filter, up=2,
                                                    padding=self.padding, flip_weight=False, fir_tail=tail)
