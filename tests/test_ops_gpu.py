@@ -418,3 +418,59 @@ def test_fused_up_synthesis_layer(dev):
         for name, f_, u_, r_ in zip(["y", "dx", "dw_latent", "dweight", "dbias", "dnoise_strength", "daffine"], res["fused"], res["unfused"], ref):
             ef, eu = err(f_, r_), err(u_, r_)
             assert ef <= 1.5 * eu + 5e-3, f"up layer {name} ({noise_kind}, clamp {clamp}): fused {ef:.3e} vs composition {eu:.3e}"
+
+
+def test_master_weight_convolutions(dev):
+    """fp32 parameter + 16-bit activations ("mixed" launches): same forward bits as casting `w * gain` first, gradients against fp64,
+    R1-style double backward, the packed-operand cache following in-place parameter updates, channels_last parameters."""
+    torch.manual_seed(11)
+    for (cin, cout, k, stride, transpose, cl) in [(16, 24, 3, 1, False, False), (24, 16, 3, 2, False, True), (16, 24, 3, 2, True, False), (8, 3, 1, 1, False, False)]:
+        gain = 0.37
+        x = torch.randn(2, cin, 12, 12, device=dev)
+        wshape = [cin, cout, k, k] if transpose else [cout, cin, k, k]
+        w = torch.nn.Parameter(torch.randn(wshape, device=dev).to(memory_format=torch.channels_last if cl else torch.contiguous_format))
+        xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        fn = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
+        y_mixed = fn(xb, w, stride=stride, padding=k // 2, wgain=gain)
+        y_cast = fn(xb, (w * gain).to(torch.bfloat16), stride=stride, padding=k // 2)
+        assert torch.equal(y_mixed, y_cast)
+        dy = torch.randn_like(y_mixed)
+        dx, dw = torch.autograd.grad((y_mixed * dy).sum(), [xb, w])
+        assert dw.dtype == torch.float32 and dw.shape == w.shape and dw.stride() == w.stride()
+        x64 = xb.detach().double().requires_grad_(True)
+        w64 = (w.detach() * gain).to(torch.bfloat16).double().requires_grad_(True)
+        f64 = torch.nn.functional.conv_transpose2d if transpose else torch.nn.functional.conv2d
+        y64 = f64(x64.cpu(), w64.cpu(), stride=stride, padding=k // 2)
+        dx64, dw64 = torch.autograd.grad((y64 * dy.double().cpu()).sum(), [x64, w64])
+        assert float((dw.double().cpu() - dw64.cpu() * gain).abs().max() / (dw64.abs().max() * gain)) < 2e-3       # fp32 accumulate of bf16 products
+        assert float((dx.double().cpu() - dx64.cpu()).abs().max() / dx64.abs().max()) < 2e-2
+        # cache follows the parameter's version counter
+        with torch.no_grad():
+            w.mul_(2.0)
+        assert torch.equal(fn(xb, w, stride=stride, padding=k // 2, wgain=gain), fn(xb, (w * gain).to(torch.bfloat16), stride=stride, padding=k // 2))
+    # double backward through the mixed path (what R1 does with the discriminator's convolutions)
+    w = torch.nn.Parameter(torch.randn(8, 8, 3, 3, device=dev))
+    xb = torch.randn(2, 8, 8, 8, device=dev).to(torch.bfloat16).requires_grad_(True)
+    for wt, kw in ((w, dict(wgain=0.5)), ((w * 0.5).to(torch.bfloat16), {})):
+        y = conv2d_gradfix.conv2d(xb, wt, padding=1, **kw)
+        g, = torch.autograd.grad(y.float().square().sum(), xb, create_graph=True)
+        gw, = torch.autograd.grad(g.float().square().sum(), w)
+        if kw:
+            ref_gw = gw
+    assert float((ref_gw - gw).abs().max() / gw.abs().max()) < 3e-2
+
+
+def test_demod_coefficients_kernel(dev):
+    from style_big_gan_amd.torch_utils.ops import modconv
+    from style_big_gan_amd.train_parts.generators import demod_coefficients
+    torch.manual_seed(12)
+    for (n, o, i, k) in [(4, 32, 24, 3), (3, 512, 512, 3), (2, 16, 64, 1)]:
+        w = torch.nn.Parameter(torch.randn(o, i, k, k, device=dev) * 0.1)
+        s = (torch.randn(n, i, device=dev) + 1).requires_grad_(True)
+        d_ref = demod_coefficients(w, s)                                   # torch composition (arbitrarily differentiable)
+        d = modconv.demod_coefs(w, s, torch.bfloat16)
+        assert float((d - d_ref).abs().max() / d_ref.abs().max()) < 1e-5
+        g = torch.randn_like(d)
+        gw_ref, gs_ref = torch.autograd.grad((d_ref * g).sum(), [w, s])
+        gw, gs = torch.autograd.grad((d * g).sum(), [w, s])
+        assert float((gw - gw_ref).abs().max() / gw_ref.abs().max()) < 1e-4 and float((gs - gs_ref).abs().max() / gs_ref.abs().max()) < 1e-4
