@@ -154,6 +154,38 @@ class StepEngine:
             adjust = np.sign(self.ada_stats['Loss/signs/real'] - self.ada_target) * (self.batch * self.world_size * self.ada_interval) / (self.ada_kimg * 1000)
             self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp_(min=0))
 
+    # -- snapshot / resume (reference trainers.py:636-656 pickles whole modules; here plain state dicts + counters) ---------
+    def state_dict(self):
+        """Everything needed to continue the run: networks, the augmentation pipe's strength, optimizer moments (a superset of the
+        reference's snapshot, which drops the optimizers) and the progress counters -- tensors and plain containers only, so the file
+        loads with ``torch.load(..., weights_only=True)``."""
+        opts = {}
+        for ph in self.phases:
+            opts.setdefault(ph.name[0], ph.opt.state_dict())       # 'G' / 'D': main and lazy-reg phases share one optimizer
+        out = dict(G=self.G.state_dict(), D=self.D.state_dict(), optimizers=opts,
+                   progress=dict(cur_nimg=int(self.cur_nimg), batch_idx=int(self.batch_idx)))
+        if self.G_ema is not None:
+            out['G_ema'] = self.G_ema.state_dict()
+        if self.augment_pipe is not None:
+            out['augment_pipe'] = self.augment_pipe.state_dict()
+        return out
+
+    def load_state_dict(self, state, strict=True, networks_only=False):
+        """`networks_only`: transfer learning (reference :350-366 -- weights are copied, the schedule restarts)."""
+        self.G.load_state_dict(state['G'], strict=strict)
+        self.D.load_state_dict(state['D'], strict=strict)
+        if self.G_ema is not None:
+            self.G_ema.load_state_dict(state.get('G_ema', state['G']), strict=strict)
+        if self.augment_pipe is not None and 'augment_pipe' in state and not networks_only:
+            self.augment_pipe.load_state_dict(state['augment_pipe'], strict=strict)
+        if networks_only:
+            return
+        for ph in self.phases:
+            if ph.name[0] in state.get('optimizers', {}):
+                ph.opt.load_state_dict(state['optimizers'][ph.name[0]])
+        self.cur_nimg = int(state['progress']['cur_nimg'])
+        self.batch_idx = int(state['progress']['batch_idx'])
+
     @torch.no_grad()
     def update_ema(self):
         """G_ema <- lerp(G, G_ema, beta), buffers copied (reference :752-761)"""
@@ -216,8 +248,12 @@ class BaseTrainer:
         if config.data.dataset != "synthetic":
             raise NotImplementedError("dataset loading is outside this build's hot path: run with data.dataset=synthetic "
                                       "(data.resolution=<R> data.num_classes=<K>)")
-        if config.trans.resume != "noresume":
-            raise NotImplementedError("snapshot resume is outside this build's hot path")
+        self.resume_path = None if config.trans.resume == "noresume" else str(config.trans.resume)     # a network-snapshot-*.pt of this build
+        if self.resume_path is not None and not os.path.isfile(self.resume_path):
+            raise ValueError(f"trans.resume={self.resume_path}: no such snapshot file (named transfer-learning sources are URL fetches and "
+                             "reference .pkl snapshots are pickled modules; neither is loaded here -- pass a .pt written by save_snapshot)")
+        self.run_dir = os.path.join(str(config.log.output), str(config.exp.name)) if config.exp.get("name", utils.MISSING) != utils.MISSING else None
+        self.snapshot_iterations = None     # iterations between snapshots; None = only on request
         self.config = config
         self.num_gpus, self.batch_size, self.batch_gpu = gpus, gen.batch, batch_gpu
         self.dataset = SyntheticDataset(int(config.data.get("resolution", 32)), 3,
@@ -319,6 +355,34 @@ class BaseTrainer:
 
     def setup_augmentations(self):
         self.augment_pipe = self.engine.augment_pipe        # built by StepEngine (it owns the loss object the pipe plugs into)
+        if self.resume_path is not None:    # networks, pipe and optimizers exist now: continue from the snapshot
+            self.resume(self.resume_path)
+
+    def save_snapshot(self, cur_nimg=None, run_dir=None):
+        """network-snapshot-<kimg>.pt + training_options.json with `start_options` (reference :636-656, :821-832).  Rank 0 writes."""
+        run_dir = run_dir or self.run_dir
+        assert run_dir is not None, "save_snapshot needs exp.name / log.output or an explicit run_dir"
+        cur_nimg = self.engine.cur_nimg if cur_nimg is None else cur_nimg
+        path = os.path.join(run_dir, f"network-snapshot-{cur_nimg // 1000:06d}.pt")
+        if self.rank == 0:
+            import json
+            os.makedirs(run_dir, exist_ok=True)
+            state = self.engine.state_dict()
+            torch.save(state, path)
+            options = dict(start_options=dict(cur_nimg=int(self.engine.cur_nimg), batch_idx=int(self.engine.batch_idx)),
+                           snapshot=os.path.basename(path), num_gpus=self.num_gpus, batch_size=self.batch_size, batch_gpu=self.batch_gpu)
+            with open(os.path.join(run_dir, "training_options.json"), "wt") as f:
+                json.dump(options, f, indent=2)
+        return path
+
+    def resume(self, path, networks_only=False):
+        state = torch.load(path, map_location=self.engine.device, weights_only=True)
+        self.engine.load_state_dict(state, networks_only=networks_only)
+        if self.num_gpus > 1:       # every rank read the same file; keep the data-parallel invariant explicit
+            for module in (self.engine.G, self.engine.D):
+                for t in list(module.parameters()) + list(module.buffers()):
+                    torch.distributed.broadcast(t.detach(), src=0)
+        return state["progress"]
 
     def distrib_acrros_gpu(self):
         pass        # StepEngine wraps its modules in GradReducer at construction (broadcast of rank 0's weights included)
@@ -337,6 +401,8 @@ class BaseTrainer:
             img, c = self.dataset.batch(eng.batch, eng.device)
             eng.train_iteration(img.to(torch.float32) / 127.5 - 1, c)
             it += 1
+            if self.snapshot_iterations and it % self.snapshot_iterations == 0:
+                self.save_snapshot()
             if max_iterations is None and total >= 0 and eng.cur_nimg >= total:
                 break
         self.stats.update()

@@ -97,3 +97,29 @@ def test_dcgan_config_runs_on_cpu(tmp_path):
     assert all(torch.isfinite(p).all() for p in trainer.engine.G.parameters())
     dry = starter.main(argv + ["exp.dry_run=true"])
     assert not hasattr(dry, "engine")
+
+
+def test_snapshot_and_resume(tmp_path):
+    """save_snapshot -> a weights-only loadable file + training_options.json; a fresh trainer resumed from it holds the same networks,
+    optimizer moments and counters, and continues from there"""
+    if torch.cuda.is_available():
+        pytest.skip("plumbing test is for the CPU container")
+    import json
+    argv = _write(tmp_path, "dcgan.yaml", DCGAN_LIKE) + ["gen.batch=16", "gen.batch_gpu=16", "data.dataset=synthetic", "data.resolution=32", "gen.kimg=1"]
+    a = starter.main(argv, max_iterations=2)
+    path = a.save_snapshot(run_dir=str(tmp_path / "run"))
+    assert os.path.basename(path) == "network-snapshot-000000.pt"
+    opts = json.load(open(tmp_path / "run" / "training_options.json"))
+    assert opts["start_options"] == {"cur_nimg": 32, "batch_idx": 2} and opts["snapshot"] == os.path.basename(path)
+    state = torch.load(path, weights_only=True)
+    assert set(state) >= {"G", "D", "optimizers", "progress"} and set(state["optimizers"]) == {"G", "D"}
+    b = starter.main(argv + [f"trans.resume={path}"], max_iterations=0)
+    assert b.engine.batch_idx == 2 and b.engine.cur_nimg == 32
+    for pa, pb in zip(list(a.engine.G.parameters()) + list(a.engine.D.parameters()), list(b.engine.G.parameters()) + list(b.engine.D.parameters())):
+        assert torch.equal(pa, pb)
+    sa, sb = a.engine.phases[0].opt.state_dict()["state"], b.engine.phases[0].opt.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) for k in sa)
+    b.training_loop(max_iterations=1)
+    assert b.engine.batch_idx == 3 and b.engine.cur_nimg == 48
+    with pytest.raises(ValueError):
+        starter.main(argv + ["trans.resume=/nonexistent/file.pt"], max_iterations=1)
