@@ -241,6 +241,21 @@ int sbg_demod_coefs_bwd(const float* g, const float* dcoefs, const float* styles
                         int N, int O, int I, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ToRGB layer (train_parts/generators.py:344-348: modulated 1x1 convolution without demodulation to <= 4 channels + linear bias_act
+ * with clamp) as streaming kernels over channel-minor 16-bit x [N, HW, C]:
+ *   fwd: y[n, o, p] = clamp(sum_c x[n, p, c] * wmod[n, o, c] + bias[o])      y fp32 planar [N, O, HW]; wmod = w[o, c] * styles[n, c], fp32
+ *   bwd: d1 = dy masked by the clamp (from the saved y);  dx[n, p, c] = sum_o d1 * wmod  (may be NULL);
+ *        partial[n][blk][o * C + c] = per-workgroup sums of d1[o, p] * x[p, c], then O sums of d1 -- the caller adds the
+ *        sbg_torgb_bwd_blocks(N, C, HW) slabs in a fixed order (reproducible) to get d wmod [N, O, C] and d bias.
+ * C = 8 * 2^k <= 512, O <= 4 (sbg_torgb_supported).  clamp < 0 disables clamping. */
+int sbg_torgb_supported(int C, int O);
+int sbg_torgb_bwd_blocks(int N, int C, int64_t HW);
+int sbg_torgb_fwd(const void* x, const float* wmod, const float* bias, float* y, int dtype, int N, int C, int O, int64_t HW,
+                  float clamp, sbg_stream_t stream);
+int sbg_torgb_bwd(const void* x, const float* wmod, const float* dy, const float* y, void* dx, float* partial, int dtype,
+                  int N, int C, int O, int64_t HW, float clamp, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * ADA augmentation pipe, device ops (train_parts/augmentations.py:121-433).
  *
  * grid_sample: bilinear, zero padding, align_corners = False -- the one mode of the reference's
@@ -288,7 +303,7 @@ int sbg_filter1d_batch(const float* x, const float* taps, float* y, int M, int H
  * (or the number pending when out == NULL). */
 enum sbg_kernel_kind {
     SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
-    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13, SBG_K_WEIGHT_PREP = 14
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13, SBG_K_WEIGHT_PREP = 14, SBG_K_TORGB = 15
 };
 typedef struct sbg_prof_record {
     int    kind;            /* enum sbg_kernel_kind */

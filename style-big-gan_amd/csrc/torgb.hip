@@ -1,0 +1,211 @@
+// torgb.hip -- the ToRGB layer as streaming kernels.
+//
+// ToRGBLayer.forward (train_parts/generators.py:344-348) = modulated 1x1 convolution without demodulation to 3 channels + linear
+// bias_act with clamp:  y[n, o, p] = clamp(sum_c x[n, c, p] * (w[o, c] * s[n, c]) + b[o]).  With O = 3 this is not matrix-core work:
+// a GEMM tile is >= 97 % padding, and the implicit-GEMM path additionally needs the modulated copy x * s.  Here the per-sample
+// weights wmod[n, o, c] = w[o, c] * s[n, c] (a [N, O, C] tensor, formed by the host so autograd splits its gradient into dw and ds)
+// are applied while x streams through once:
+//   forward : read x (channel-minor 16-bit), write y (planar fp32)                        -- HBM-bound, numel(x) * 2 B
+//   backward: read x and dy, write dx = sum_o d1[o] * wmod[n, o, c] and the partial sums of dwmod[n, o, c] = sum_p d1[o, p] * x[c, p],
+//             dbias[o] = sum d1[o, p]  (d1 = dy masked by the clamp, from the saved y)     -- HBM-bound, numel(x) * 4 B
+// Lane mapping: a pixel's C channels are contiguous (C * 2 bytes); C / 8 lanes share a pixel with 8 channels (16 B) each, so a
+// wavefront covers 64 / (C / 8) pixels per load.  C / 8 must be a power of two <= 64 (C = 8 ... 512), O <= 4.
+#include "sbg_common.h"
+
+namespace {
+
+constexpr int MAX_O = 4;
+
+struct RgbArgs {
+    const void* x; const float* wmod; const float* bias; const float* dy; const float* ysaved;
+    float* y; void* dx; float* partial;
+    int N, C, O; int64_t HW;
+    float clamp;
+    int blocks_per_n;
+};
+
+template <class T>
+__global__ void __launch_bounds__(256) torgb_fwd_kernel(RgbArgs p)
+{
+    const int lpp = p.C >> 3;                       // lanes per pixel
+    const int ppw = 64 / lpp;                       // pixels per wavefront load
+    const int n = blockIdx.x / p.blocks_per_n, blk = blockIdx.x % p.blocks_per_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & (lpp - 1), pl = lane / lpp;
+    float w[MAX_O][8];
+#pragma unroll
+    for (int o = 0; o < MAX_O; o++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[o][j] = o < p.O ? p.wmod[((int64_t)n * p.O + o) * p.C + cl * 8 + j] : 0.0f;
+    const T* xb = (const T*)p.x + (int64_t)n * p.HW * p.C;
+    float* yb = p.y + (int64_t)n * p.O * p.HW;
+    const int64_t stride = (int64_t)p.blocks_per_n * 4 * ppw;
+    for (int64_t pix0 = ((int64_t)blk * 4 + wave) * ppw; pix0 < p.HW; pix0 += stride) {
+        const int64_t pix = pix0 + pl;
+        float acc[MAX_O] = {0.f, 0.f, 0.f, 0.f};
+        if (pix < p.HW) {
+            float v[8];
+            Vec8<T>::ld(xb + pix * p.C + cl * 8, v);
+#pragma unroll
+            for (int o = 0; o < MAX_O; o++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[o] += v[j] * w[o][j];
+        }
+        for (int m = lpp >> 1; m >= 1; m >>= 1)
+#pragma unroll
+            for (int o = 0; o < MAX_O; o++) acc[o] += __shfl_xor(acc[o], m, 64);
+        if (cl == 0 && pix < p.HW) {
+#pragma unroll
+            for (int o = 0; o < MAX_O; o++)
+                if (o < p.O) {
+                    float r = acc[o] + (p.bias ? p.bias[o] : 0.0f);
+                    if (p.clamp >= 0.0f) r = fminf(fmaxf(r, -p.clamp), p.clamp);
+                    yb[(int64_t)o * p.HW + pix] = r;
+                }
+        }
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) torgb_bwd_kernel(RgbArgs p)
+{
+    __shared__ float red[4][64][MAX_O * 8 + 1];     // per-wave copies of the lane accumulators for the cross-lane / cross-wave sum
+    __shared__ float redb[4][64][MAX_O];
+    const int lpp = p.C >> 3, ppw = 64 / lpp;
+    const int n = blockIdx.x / p.blocks_per_n, blk = blockIdx.x % p.blocks_per_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & (lpp - 1), pl = lane / lpp;
+    float w[MAX_O][8];
+#pragma unroll
+    for (int o = 0; o < MAX_O; o++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) w[o][j] = o < p.O ? p.wmod[((int64_t)n * p.O + o) * p.C + cl * 8 + j] : 0.0f;
+    const T* xb = (const T*)p.x + (int64_t)n * p.HW * p.C;
+    T* dxb = (T*)p.dx + (int64_t)n * p.HW * p.C;
+    const float* dyb = p.dy + (int64_t)n * p.O * p.HW;
+    const float* ysb = p.ysaved + (int64_t)n * p.O * p.HW;
+    float dw[MAX_O][8];
+    float db[MAX_O] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < MAX_O; o++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) dw[o][j] = 0.0f;
+    const int64_t stride = (int64_t)p.blocks_per_n * 4 * ppw;
+    for (int64_t pix0 = ((int64_t)blk * 4 + wave) * ppw; pix0 < p.HW; pix0 += stride) {
+        const int64_t pix = pix0 + pl;
+        if (pix >= p.HW) continue;
+        float d1[MAX_O];
+#pragma unroll
+        for (int o = 0; o < MAX_O; o++) {
+            d1[o] = 0.0f;
+            if (o < p.O) {
+                const float g = dyb[(int64_t)o * p.HW + pix];
+                const float yv = ysb[(int64_t)o * p.HW + pix];
+                d1[o] = (p.clamp >= 0.0f && !(fabsf(yv) < p.clamp)) ? 0.0f : g;      // clamp gradient: zero where the output sits on the rail (bias_act.cu:141)
+            }
+        }
+        float v[8], dxv[8];
+        Vec8<T>::ld(xb + pix * p.C + cl * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float a = 0.0f;
+#pragma unroll
+            for (int o = 0; o < MAX_O; o++) { a += d1[o] * w[o][j]; dw[o][j] += d1[o] * v[j]; }
+            dxv[j] = a;
+        }
+        if (p.dx) Vec8<T>::st(dxb + pix * p.C + cl * 8, dxv);
+        if (cl == 0) {
+#pragma unroll
+            for (int o = 0; o < MAX_O; o++) db[o] += d1[o];
+        }
+    }
+    // block reduction in a fixed order: lanes with the same channel group (cl) over pl, then the four waves
+#pragma unroll
+    for (int o = 0; o < MAX_O; o++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) red[wave][lane][o * 8 + j] = dw[o][j];
+        redb[wave][lane][o] = db[o];
+    }
+    __syncthreads();
+    // partial layout: [N][blocks_per_n][O * C + O]
+    float* out = p.partial + ((int64_t)n * p.blocks_per_n + blk) * ((int64_t)p.O * p.C + p.O);
+    for (int idx = threadIdx.x; idx < p.O * p.C; idx += 256) {
+        const int o = idx / p.C, c = idx % p.C;
+        const int g = c >> 3, j = c & 7;
+        float s = 0.0f;
+        for (int wv = 0; wv < 4; wv++)
+            for (int q = 0; q < ppw; q++) s += red[wv][q * lpp + g][o * 8 + j];
+        out[idx] = s;
+    }
+    if (threadIdx.x < p.O) {
+        float s = 0.0f;
+        for (int wv = 0; wv < 4; wv++)
+            for (int q = 0; q < ppw; q++) s += redb[wv][q * lpp][threadIdx.x];
+        out[(int64_t)p.O * p.C + threadIdx.x] = s;
+    }
+}
+
+static int check_shape(int N, int C, int O, int64_t HW)
+{
+    const int lpp = C >> 3;
+    SBG_CHECK(N >= 1 && HW >= 1 && O >= 1 && O <= MAX_O, "torgb: bad sizes (O <= %d)", MAX_O);
+    SBG_CHECK(C >= 8 && C <= 512 && (C & 7) == 0 && (lpp & (lpp - 1)) == 0, "torgb: C must be 8 * 2^k <= 512");
+    SBG_CHECK((int64_t)N * C * HW <= INT32_MAX, "torgb: tensors are limited to INT_MAX elements");
+    return 0;
+}
+
+static int blocks_for(int N, int C, int64_t HW)
+{
+    const int ppw = 64 / (C >> 3);
+    int64_t want = (HW + 4 * ppw * 8 - 1) / (4 * ppw * 8);      // >= 8 pixel groups per wavefront
+    int64_t cap = (256 * 8 + N - 1) / N;                        // ~2048 workgroups in total
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+}  // namespace
+
+extern "C" int sbg_torgb_supported(int C, int O)
+{
+    const int lpp = C >> 3;
+    return (O >= 1 && O <= MAX_O && C >= 8 && C <= 512 && (C & 7) == 0 && (lpp & (lpp - 1)) == 0) ? 1 : 0;
+}
+
+extern "C" int sbg_torgb_bwd_blocks(int N, int C, int64_t HW) { return blocks_for(N, C, HW); }
+
+extern "C" int sbg_torgb_fwd(const void* x, const float* wmod, const float* bias, float* y, int dtype, int N, int C, int O, int64_t HW,
+                             float clamp, sbg_stream_t stream_)
+{
+    SBG_CHECK(x && wmod && y, "torgb_fwd: null pointer");
+    if (int rc = check_shape(N, C, O, HW)) return rc;
+    SBG_CHECK(dtype == SBG_BF16 || dtype == SBG_F16, "torgb_fwd: 16-bit activations only");
+    RgbArgs a = {};
+    a.x = x; a.wmod = wmod; a.bias = bias; a.y = y; a.N = N; a.C = C; a.O = O; a.HW = HW; a.clamp = clamp;
+    a.blocks_per_n = blocks_for(N, C, HW);
+    hipStream_t stream = (hipStream_t)stream_;
+    SbgProfScope prof(stream, SBG_K_TORGB, 2.0 * N * O * (double)C * HW, (double)N * HW * (2.0 * C + 4.0 * O), {N, C, O, (int)HW, 0, 0, 0});
+    dim3 grid((unsigned)(N * a.blocks_per_n)), block(256);
+    if (dtype == SBG_BF16) hipLaunchKernelGGL(torgb_fwd_kernel<bf16_s>, grid, block, 0, stream, a);
+    else                   hipLaunchKernelGGL(torgb_fwd_kernel<f16_s>, grid, block, 0, stream, a);
+    SBG_HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sbg_torgb_bwd(const void* x, const float* wmod, const float* dy, const float* y, void* dx, float* partial, int dtype,
+                             int N, int C, int O, int64_t HW, float clamp, sbg_stream_t stream_)
+{
+    SBG_CHECK(x && wmod && dy && y && partial, "torgb_bwd: null pointer");
+    if (int rc = check_shape(N, C, O, HW)) return rc;
+    SBG_CHECK(dtype == SBG_BF16 || dtype == SBG_F16, "torgb_bwd: 16-bit activations only");
+    RgbArgs a = {};
+    a.x = x; a.wmod = wmod; a.dy = dy; a.ysaved = y; a.dx = dx; a.partial = partial; a.N = N; a.C = C; a.O = O; a.HW = HW; a.clamp = clamp;
+    a.blocks_per_n = blocks_for(N, C, HW);
+    hipStream_t stream = (hipStream_t)stream_;
+    SbgProfScope prof(stream, SBG_K_TORGB, 4.0 * N * O * (double)C * HW, (double)N * HW * (4.0 * C + 8.0 * O), {N, C, O, (int)HW, 1, 0, 0});
+    dim3 grid((unsigned)(N * a.blocks_per_n)), block(256);
+    if (dtype == SBG_BF16) hipLaunchKernelGGL(torgb_bwd_kernel<bf16_s>, grid, block, 0, stream, a);
+    else                   hipLaunchKernelGGL(torgb_bwd_kernel<f16_s>, grid, block, 0, stream, a);
+    SBG_HIP_LAUNCH_CHECK();
+    return 0;
+}

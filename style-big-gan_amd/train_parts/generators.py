@@ -22,7 +22,7 @@ import torch
 
 from .. import utils
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, conv_bias_act, modconv, modulate, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, conv_bias_act, modconv, modulate, torgb, upfirdn2d
 
 generators = utils.ClassRegistry()
 
@@ -309,6 +309,9 @@ class ToRGBLayer(torch.nn.Module):
 
     def forward(self, x, w, fused_modconv=True):
         styles = self.affine(w) * self.weight_gain
+        if torgb.usable(x, self.weight):        # first-order passes: x streams once through per-sample weights (ops/torgb.py); fp32 planar result
+            wmod = self.weight.reshape(1, self.weight.shape[0], -1) * styles.to(torch.float32).unsqueeze(1)
+            return torgb.torgb(x, wmod, self.bias, clamp=self.conv_clamp)
         if conv_bias_act.fusable(x, self.weight, 'linear'):      # modulation pass, then 1x1 convolution with bias + clamp in its epilogue
             xs = modulate.scale_nc(x, styles)
             wt = self.weight if conv2d_gradfix.is_mixed(x, self.weight) else self.weight.to(x.dtype)

@@ -474,3 +474,27 @@ def test_demod_coefficients_kernel(dev):
         gw_ref, gs_ref = torch.autograd.grad((d_ref * g).sum(), [w, s])
         gw, gs = torch.autograd.grad((d * g).sum(), [w, s])
         assert float((gw - gw_ref).abs().max() / gw_ref.abs().max()) < 1e-4 and float((gs - gs_ref).abs().max() / gs_ref.abs().max()) < 1e-4
+
+
+def test_torgb_streaming_kernels(dev):
+    """ops/torgb.py vs the fp64 composition clamp(conv1x1(x * s, w) + b): output, dx, d wmod (-> dw, ds), db; clamp mask; ragged pixel counts"""
+    from style_big_gan_amd.torch_utils.ops import torgb
+    torch.manual_seed(13)
+    for (n, c, o, h, w, clamp) in [(3, 128, 3, 16, 16, 0.8), (2, 512, 3, 8, 8, None), (2, 64, 3, 17, 13, 0.5), (4, 32, 1, 9, 9, 256.0), (2, 8, 4, 5, 7, None)]:
+        x = torch.randn(n, c, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wt = (torch.randn(o, c, 1, 1, device=dev) / c ** 0.5).requires_grad_(True)
+        s = (torch.randn(n, c, device=dev) * 0.5 + 1).requires_grad_(True)
+        b = torch.randn(o, device=dev).requires_grad_(True)
+        assert torgb.usable(x, wt)
+        wmod = wt.reshape(1, o, c) * s.unsqueeze(1)
+        y = torgb.torgb(x, wmod, b, clamp=clamp)
+        assert y.dtype == torch.float32 and y.shape == (n, o, h, w) and y.is_contiguous()
+        dy = torch.randn_like(y)
+        gx, gw, gs, gb = torch.autograd.grad((y * dy).sum(), [x, wt, s, b])
+        x64, w64, s64, b64 = (t.detach().double().cpu().requires_grad_(True) for t in (x, wt, s, b))
+        pre = torch.einsum('nchw,oc,nc->nohw', x64, w64[:, :, 0, 0], s64) + b64.reshape(1, -1, 1, 1)
+        y64 = pre.clamp(-clamp, clamp) if clamp is not None else pre
+        r = torch.autograd.grad((y64 * dy.double().cpu()).sum(), [x64, w64, s64, b64])
+        rel = lambda a, ref: float((a.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-12))
+        assert rel(y, y64) < 1e-5, (c, rel(y, y64))
+        assert rel(gx, r[0]) < 1e-2 and rel(gw, r[1]) < 1e-4 and rel(gs, r[2]) < 1e-4 and rel(gb, r[3]) < 1e-5, (c, rel(gx, r[0]), rel(gw, r[1]), rel(gs, r[2]))
