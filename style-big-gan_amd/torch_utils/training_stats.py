@@ -31,11 +31,35 @@ def report(name, value):
     v = torch.as_tensor(value)
     if v.numel() == 0:
         return value
-    v = v.detach().flatten().to(_DTYPE)
-    m = torch.stack([torch.ones_like(v).sum(), v.sum(), v.square().sum()])
-    dev = m.device
-    slot[dev] = slot[dev] + m if dev in slot else m
+    # The reference reduces every reported tensor to its three moments on the spot (eight launches of a few numbers each, ~20 reports per
+    # iteration).  Here the (small) tensor is parked and the moments are formed once per name when a Collector asks for them.
+    v = v.detach().flatten()
+    dev = v.device
+    entry = slot.get(dev)
+    if entry is None:
+        entry = slot[dev] = [None, []]          # [moments accumulated so far, parked tensors]
+    if v.numel() <= 65536:
+        entry[1].append(v.clone())
+        if len(entry[1]) >= 64:
+            _fold(entry)
+    else:
+        m = _moments(v)
+        entry[0] = m if entry[0] is None else entry[0] + m
     return value
+
+
+def _moments(v):
+    v = v.to(_DTYPE)
+    return torch.stack([torch.full([], float(v.numel()), dtype=_DTYPE, device=v.device), v.sum(), v.square().sum()])
+
+
+def _fold(entry):
+    """entry = [moments | None, parked tensors] -> moments of everything reported so far (None if nothing); empties the parking list"""
+    parked, entry[1] = entry[1], []
+    if parked:
+        m = _moments(torch.cat([t.to(_DTYPE) for t in parked]) if len(parked) > 1 else parked[0])
+        entry[0] = m if entry[0] is None else entry[0] + m
+    return entry[0]
 
 
 def report0(name, value):
@@ -51,8 +75,10 @@ def _sync(names):
     rows = []
     for name in names:
         total = torch.zeros([_MOMENTS], dtype=_DTYPE, device=dev)
-        for m in _pending.get(name, {}).values():
-            total = total + m.to(dev)
+        for entry in _pending.get(name, {}).values():
+            m = _fold(entry)
+            if m is not None:
+                total = total + m.to(dev)
         _pending[name] = dict()
         rows.append(total)
     delta = torch.stack(rows)
