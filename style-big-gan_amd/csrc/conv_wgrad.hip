@@ -49,6 +49,21 @@ struct WgradArgs {
     int ntaps_total;
 };
 
+// Workgroup -> (a tile, b tile, pixel split).  Workgroups are dealt round-robin to the eight XCDs, each with its own L2: all channel
+// tiles of one pixel split are therefore placed on ONE XCD, back to back, so the split's a / b pixels come from HBM once and the
+// other tiles hit that L2 (with a plain (x, y, z) grid the tiles of a split land on all eight L2s and the 256-channel layers
+// measured 3x their algorithmic HBM bytes: profiles/r01j_traffic.json, FETCH_SIZE).  Returns false for the padding workgroups.
+static __device__ __forceinline__ bool wgrad_decode_block(const WgradArgs& p, int& ta, int& tb, int& split)
+{
+    const int T = p.atiles * p.btiles;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int tile = j % T;
+    split = (j / T) * 8 + xcd;
+    ta = tile % p.atiles; tb = tile / p.atiles;
+    return split < p.nsplit;
+}
+static inline unsigned wgrad_grid(const WgradArgs& a) { return 8u * (unsigned)(a.atiles * a.btiles) * (unsigned)((a.nsplit + 7) / 8); }
+
 typedef __attribute__((address_space(3))) short4_t* lds_s4_ptr;
 
 // transposing LDS read: lane (16-lane group, 4q+p) passes the address of row q, columns 4p..4p+3; lane i gets column i of
@@ -74,7 +89,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
     unsigned char* sB = smem + A_BYTES;                 // NT tiles
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ca0 = blockIdx.x * BCA, cb0 = blockIdx.y * BCB, split = blockIdx.z;
+    int ta_, tb_, split;
+    if (!wgrad_decode_block(p, ta_, tb_, split)) return;       // (uniform per workgroup, before any barrier)
+    const int ca0 = ta_ * BCA, cb0 = tb_ * BCB;
     const int chunk_begin = split * p.chunks_per_split;
     int chunk_end = chunk_begin + p.chunks_per_split;
     if (chunk_end > p.nchunks) chunk_end = p.nchunks;
@@ -234,7 +251,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ca0 = blockIdx.x * BCA, cb0 = blockIdx.y * BCB, split = blockIdx.z;
+    int ta_, tb_, split;
+    if (!wgrad_decode_block(p, ta_, tb_, split)) return;       // (uniform per workgroup, before any barrier)
+    const int ca0 = ta_ * BCA, cb0 = tb_ * BCB;
     const int chunk_begin = split * p.chunks_per_split;
     int chunk_end = chunk_begin + p.chunks_per_split;
     if (chunk_end > p.nchunks) chunk_end = p.nchunks;
@@ -446,7 +465,7 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t stream)
     SbgProfScope prof(stream, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                       2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
                       {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, BCA * 1000 + BCB});
-    hipLaunchKernelGGL(kern, dim3(a.atiles, a.btiles, a.nsplit), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(wgrad_grid(a)), dim3(256), lds, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -503,7 +522,7 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
         SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                           2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
                           {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, bca * 1000 + 64});
-        const dim3 grid(a.atiles, a.btiles, a.nsplit);
+        const dim3 grid(wgrad_grid(a));
 #define SBG_ROWS_LAUNCH(MFT, SS, BB, NS) hipLaunchKernelGGL((conv_wgrad_rows_kernel<MFT, SS, BB, NS>), grid, dim3(512), lds, s, a, ab, bb)
         if (s_ == 1 && bca == 64)       { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 64, 3);  else SBG_ROWS_LAUNCH(f16_mfma, 1, 64, 3); }
         else if (s_ == 1)               { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 128, 3); else SBG_ROWS_LAUNCH(f16_mfma, 1, 128, 3); }
