@@ -256,6 +256,20 @@ int sbg_torgb_bwd(const void* x, const float* wmod, const float* dy, const float
                   int N, int C, int O, int64_t HW, float clamp, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * fromRGB layer of the discriminator (train_parts/discriminators.py:270-277 -> Conv2dLayer :115-124: 1x1 convolution from <= 4 image
+ * channels + bias + activation * gain + clamp) as streaming kernels.  img fp32 planar [N, Ci, HW]; w fp32 [Co][Ci] (weight * weight_gain);
+ * y 16-bit channel-minor [N, HW, Co]; act in {linear, relu, lrelu}.
+ *   fwd: y = clamp(act(sum_c img * w + bias) * gain)
+ *   bwd: d1 = dy * d(clamp(act(.) * gain)) from the saved y;  partial[n][blk][co * Ci + c] = per-workgroup sums of d1 * img, then Co sums of
+ *        d1 (the caller adds the sbg_fromrgb_bwd_blocks(N, HW) slabs in a fixed order);  dimg[n, c, p] = sum_co d1 * w (NULL = not wanted). */
+int sbg_fromrgb_supported(int Ci, int Co, int act);
+int sbg_fromrgb_bwd_blocks(int N, int64_t HW);
+int sbg_fromrgb_fwd(const float* img, const float* w, const float* bias, void* y, int dtype, int N, int Ci, int Co, int64_t HW,
+                    int act, float alpha, float gain, float clamp, sbg_stream_t stream);
+int sbg_fromrgb_bwd(const float* img, const float* w, const void* dy, const void* y, float* dimg, float* partial, int dtype,
+                    int N, int Ci, int Co, int64_t HW, int act, float alpha, float gain, float clamp, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * ADA augmentation pipe, device ops (train_parts/augmentations.py:121-433).
  *
  * grid_sample: bilinear, zero padding, align_corners = False -- the one mode of the reference's
@@ -303,7 +317,7 @@ int sbg_filter1d_batch(const float* x, const float* taps, float* y, int M, int H
  * (or the number pending when out == NULL). */
 enum sbg_kernel_kind {
     SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
-    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13, SBG_K_WEIGHT_PREP = 14, SBG_K_TORGB = 15
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13, SBG_K_WEIGHT_PREP = 14, SBG_K_TORGB = 15, SBG_K_FROMRGB = 16
 };
 typedef struct sbg_prof_record {
     int    kind;            /* enum sbg_kernel_kind */

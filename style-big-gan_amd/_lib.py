@@ -90,7 +90,7 @@ class ProfRecord(ctypes.Structure):
 
 
 KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 9: "sn_power", 10: "attention",
-                11: "grid_sample", 12: "filter1d", 13: "color", 14: "weight_prep", 15: "torgb"}
+                11: "grid_sample", 12: "filter1d", 13: "color", 14: "weight_prep", 15: "torgb", 16: "fromrgb"}
 
 _lib = None
 _lock = threading.Lock()
@@ -130,6 +130,10 @@ SYMBOLS = [
     ("sbg_torgb_bwd_blocks", _c.c_int, [_c.c_int, _c.c_int, _c.c_int64]),
     ("sbg_torgb_fwd", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 4 + [_c.c_int64, _c.c_float, _c.c_void_p]),
     ("sbg_torgb_bwd", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int] * 4 + [_c.c_int64, _c.c_float, _c.c_void_p]),
+    ("sbg_fromrgb_supported", _c.c_int, [_c.c_int] * 3),
+    ("sbg_fromrgb_bwd_blocks", _c.c_int, [_c.c_int, _c.c_int64]),
+    ("sbg_fromrgb_fwd", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 4 + [_c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
+    ("sbg_fromrgb_bwd", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int] * 4 + [_c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
     ("sbg_grid_sample2d", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd", _c.c_int, [_c.POINTER(GridSampleParams), _c.c_void_p]),
     ("sbg_grid_sample2d_bwd_overwrites", _c.c_int, [_c.POINTER(GridSampleParams)]),

@@ -12,7 +12,7 @@ import torch
 
 from .. import utils
 from ..torch_utils import misc
-from ..torch_utils.ops import upfirdn2d
+from ..torch_utils.ops import fromrgb, upfirdn2d
 from . import generators as _g
 from .generators import Conv2dLayer, FullyConnectedLayer, MappingNetwork
 
@@ -83,8 +83,13 @@ class DiscriminatorBlock(torch.nn.Module):
 
         if self.in_channels == 0 or self.architecture == 'skip':
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
-            img = img.to(dtype=dtype, memory_format=fmt)
-            y = self.fromrgb(img)
+            fr = self.fromrgb
+            if (self.architecture != 'skip' and fr.up == 1 and fr.down == 1 and fromrgb.usable(img, fr.weight, fr.activation, dtype)):
+                # first-order passes: the fp32 image streams once through the 1x1 layer (ops/fromrgb.py), no cast / layout pass, no padded GEMM
+                y = fromrgb.fromrgb(img, fr.weight, fr.bias, fr.weight_gain, fr.activation, gain=fr.act_gain, clamp=fr.conv_clamp, out_dtype=dtype)
+            else:
+                img = img.to(dtype=dtype, memory_format=fmt)
+                y = self.fromrgb(img)
             x = x + y if x is not None else y
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
 

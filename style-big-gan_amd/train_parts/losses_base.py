@@ -11,6 +11,7 @@ import torch
 
 from .. import utils
 from ..torch_utils import misc, training_stats
+from ..torch_utils.ops import fromrgb as _fromrgb
 from ..utils import EasyDict
 from .losses import losses
 from .regularizations import discriminator_regs, generator_regs
@@ -76,6 +77,16 @@ class LossBase:
         do_Dmain = phase in ['Dmain', 'Dboth']
         do_Greg = phase in ['Greg', 'Gboth'] and self.gen_regs is not None
         do_Dreg = phase in ['Dreg', 'Dboth'] and self.dis_regs is not None
+        # discriminator regularisers (R1, gradient penalty) differentiate D twice w.r.t. its input; every other phase is first order
+        # and may use the streaming fromRGB kernels (torch_utils/ops/fromrgb.py)
+        fromrgb_was = _fromrgb.enabled
+        _fromrgb.enabled = not do_Dreg
+        try:
+            self._accumulate(phase, real_img, real_c, gen_z, gen_c, sync, gain, do_Gmain, do_Dmain, do_Greg, do_Dreg)
+        finally:
+            _fromrgb.enabled = fromrgb_was
+
+    def _accumulate(self, phase, real_img, real_c, gen_z, gen_c, sync, gain, do_Gmain, do_Dmain, do_Greg, do_Dreg):
 
         if do_Gmain:
             self.do_Gmain(real_img, real_c, gen_z, gen_c, sync=(sync and not do_Greg), gain=gain)

@@ -111,3 +111,35 @@ def test_training_step_gradients_fp32(dev, tag):
     pen.backward()
     assert abs(float(pen) - float(g.t("r1_penalty"))) < 2e-3 * max(1.0, abs(float(g.t("r1_penalty"))))
     _check_grads(D, g, "gradR1/", 4e-3)
+
+
+def test_discriminator_with_streaming_fromrgb(dev):
+    """the bf16 discriminator with ops/fromrgb.py switched on (what the loss code does in first-order phases): logits against the
+    reference's, first-order gradients (image + parameters) against the fp32 network -- held to be as close to it as the
+    switched-off bf16 composition is (two bf16 evaluation orders flip individual activation masks, so they are not compared
+    with each other; the op's own arithmetic is pinned at 1e-4 in test_ops_gpu.py)"""
+    from style_big_gan_amd.torch_utils.ops import fromrgb
+    g = Golden("networks_orig_orig_c3_clamp")
+    c = g.t("c").to(dev)
+
+    def run(D, on):
+        img = g.t("img").to(dev).requires_grad_(True)
+        fromrgb.enabled = on
+        try:
+            logits = D(img, c)
+            grads = torch.autograd.grad(torch.nn.functional.softplus(logits).sum(), [img] + [p for p in D.parameters() if p.requires_grad], allow_unused=True)
+        finally:
+            fromrgb.enabled = False
+        return logits.detach(), grads
+
+    _, D32 = build(g, dev, num_fp16_res=0)
+    _, D16 = build(g, dev, num_fp16_res=8)
+    ref = run(D32, False)
+    comp, fused = run(D16, False), run(D16, True)
+    assert max_rel(fused[0], g.t("logits")) < 6e-2
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for gr, gc, gf in zip(ref[1], comp[1], fused[1]):
+        if gr is None:
+            continue
+        ec, ef = l2(gc, gr), l2(gf, gr)
+        assert ef <= 1.5 * ec + 1e-2, (tuple(gr.shape), ec, ef)

@@ -498,3 +498,46 @@ def test_torgb_streaming_kernels(dev):
         rel = lambda a, ref: float((a.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-12))
         assert rel(y, y64) < 1e-5, (c, rel(y, y64))
         assert rel(gx, r[0]) < 1e-2 and rel(gw, r[1]) < 1e-4 and rel(gs, r[2]) < 1e-4 and rel(gb, r[3]) < 1e-5, (c, rel(gx, r[0]), rel(gw, r[1]), rel(gs, r[2]))
+
+
+def test_fromrgb_streaming_kernels(dev):
+    """ops/fromrgb.py vs the fp64 composition clamp(lrelu(conv1x1(img, w * gain) + b) * act_gain): output; dimg, dw, db against fp64 sums
+    under the op's own gradient convention (masks read from the stored 16-bit output); ragged pixel counts"""
+    from style_big_gan_amd.torch_utils.ops import fromrgb
+    torch.manual_seed(14)
+    old = fromrgb.enabled
+    fromrgb.enabled = True
+    try:
+        for (n, ci, co, h, w, act, clamp) in [(3, 3, 128, 16, 16, "lrelu", 256.0), (2, 3, 512, 8, 8, "lrelu", 0.7), (2, 1, 64, 17, 13, "relu", None),
+                                              (2, 3, 32, 9, 31, "linear", 0.5), (1, 4, 8, 5, 7, "lrelu", None)]:
+            img = torch.randn(n, ci, h, w, device=dev).requires_grad_(True)
+            wt = torch.randn(co, ci, 1, 1, device=dev).requires_grad_(True)
+            b = torch.randn(co, device=dev).requires_grad_(True)
+            wg = 1 / np.sqrt(ci)
+            assert fromrgb.usable(img, wt, act, torch.bfloat16)
+            y = fromrgb.fromrgb(img, wt, b, wg, act, clamp=clamp)
+            assert y.dtype == torch.bfloat16 and y.shape == (n, co, h, w) and y.is_contiguous(memory_format=torch.channels_last)
+            dy = torch.randn(n, co, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            gi, gw, gb = torch.autograd.grad((y.float() * dy.float()).sum(), [img, wt, b])
+            i64, w64, b64 = (t.detach().double().cpu() for t in (img, wt, b))
+            pre = torch.einsum('nchw,oc->nohw', i64, w64[:, :, 0, 0] * wg) + b64.reshape(1, -1, 1, 1)
+            a, g = {"lrelu": (0.2, np.sqrt(2)), "relu": (0.0, np.sqrt(2)), "linear": (None, 1.0)}[act]
+            z = pre if a is None else torch.where(pre > 0, pre, pre * a)
+            y64 = z * g
+            if clamp is not None:
+                y64 = y64.clamp(-clamp, clamp)
+            rel = lambda t, ref: float((t.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-12))
+            assert rel(y.detach(), y64) < 1e-2                                     # bf16 output
+            # gradient convention (bias_act.cu:141, applied to the stored 16-bit output): slope and rail test read the saved y
+            ys = y.detach().double().cpu()
+            slope = torch.full_like(ys, g) if a is None else torch.where(ys > 0, torch.full_like(ys, g), torch.full_like(ys, g * a))
+            if clamp is not None:
+                rail = float(torch.tensor(clamp).to(torch.bfloat16))
+                slope = torch.where(ys.abs() < rail, slope, torch.zeros_like(slope))
+            d1 = dy.double().cpu() * slope
+            r_i = torch.einsum('nohw,oc->nchw', d1, w64[:, :, 0, 0] * wg)
+            r_w = (torch.einsum('nohw,nchw->oc', d1, i64) * wg).reshape(co, ci, 1, 1)
+            r_b = d1.sum([0, 2, 3])
+            assert rel(gw, r_w) < 1e-4 and rel(gb, r_b) < 1e-4 and rel(gi, r_i) < 1e-4, (co, act, rel(gw, r_w), rel(gb, r_b), rel(gi, r_i))
+    finally:
+        fromrgb.enabled = old
