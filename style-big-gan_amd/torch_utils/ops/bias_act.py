@@ -80,6 +80,8 @@ def _run(x, b, xref, yref, dy, grad, cfg, fmt):
         size_b, step_b = b.shape[0], x.stride(cfg.dim)
     else:
         size_b, step_b = 0, 1
+    if x.numel() == 0:          # empty batch: nothing to launch (an empty tensor has no device pointer)
+        return y
     status = lib.sbg_bias_act(_lib.ptr(x), _lib.ptr(b), _lib.ptr(aux[0]), _lib.ptr(aux[1]), _lib.ptr(aux[2]), _lib.ptr(y),
                               _lib.dtype_code(x.dtype), grad, cfg.spec.cuda_idx, cfg.alpha, cfg.gain, cfg.clamp,
                               x.numel(), size_b, max(step_b, 1), _lib.stream_ptr(x.device))

@@ -32,6 +32,8 @@ def _scale_nc_launch(x, a, z):
         else:
             z = z.reshape(n, h * w).contiguous(); zsn = h * w
     y = torch.empty_like(x)
+    if y.numel() == 0:          # empty batch: nothing to launch
+        return y
     _lib.check(lib.sbg_scale_nc(_lib.ptr(x), _lib.ptr(a), _lib.ptr(z), _lib.ptr(y), _lib.dtype_code(x.dtype), layout,
                                 n, c, h * w, zsn, _lib.stream_ptr(x.device)), "sbg_scale_nc")
     return y
@@ -44,6 +46,8 @@ def _dot_hw_launch(u, v):
     if v is not None:
         v = v.to(u.dtype).contiguous(memory_format=torch.channels_last if layout == 1 else torch.contiguous_format)
     n, c, h, w = u.shape
+    if u.numel() == 0:          # empty batch / image: the sum over nothing
+        return torch.zeros([n, c], dtype=torch.float32, device=u.device)
     ns = lib.sbg_dot_hw_splits(layout, n, c, h * w)
     part = torch.empty([ns, n, c], dtype=torch.float32, device=u.device)
     _lib.check(lib.sbg_dot_hw(_lib.ptr(u), _lib.ptr(v), _lib.ptr(part), _lib.dtype_code(u.dtype), layout,

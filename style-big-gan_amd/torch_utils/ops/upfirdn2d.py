@@ -87,6 +87,8 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     cl = x.stride(1) == 1 and c > 1
     y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device,
                     memory_format=torch.channels_last if cl else torch.contiguous_format)
+    if y.numel() == 0 and not probe:         # empty batch: nothing to launch
+        return y
     p = _lib.UpfirdnParams()
     p.x, p.f, p.y = x.data_ptr(), f2d.data_ptr(), y.data_ptr()
     p.dtype = _lib.dtype_code(x.dtype)

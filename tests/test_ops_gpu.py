@@ -541,3 +541,32 @@ def test_fromrgb_streaming_kernels(dev):
             assert rel(gw, r_w) < 1e-4 and rel(gb, r_b) < 1e-4 and rel(gi, r_i) < 1e-4, (co, act, rel(gw, r_w), rel(gb, r_b), rel(gi, r_i))
     finally:
         fromrgb.enabled = old
+
+
+def test_maximum_sizes_and_empty_inputs(dev):
+    """The reference's plugins limit tensors to INT_MAX elements (bias_act.cpp:40, upfirdn2d.cpp:22-23,36).  Same limit here, byte offsets
+    64-bit: a bias_act just under the limit (4.3 GB of bf16) is spot-checked slice by slice, one element more is refused; empty batches
+    pass through every op."""
+    torch.manual_seed(15)
+    n_el = 2 ** 31 - 8                                  # just under INT_MAX, multiple of 8
+    c, w = 8, 4096
+    h = n_el // (c * w)
+    x = torch.empty([1, c, h, w], dtype=torch.bfloat16, device=dev)
+    for i in range(0, h, 8192):                         # fill in slabs (randn_like on the whole tensor would need 8.6 GB of fp32)
+        x[:, :, i:i + 8192] = torch.randn([1, c, min(8192, h - i), w], device=dev).to(torch.bfloat16)
+    b = torch.randn(c, device=dev).to(torch.bfloat16)
+    assert x.numel() <= 2 ** 31 - 1
+    y = bias_act.bias_act(x, b, act="lrelu", clamp=1.5)
+    for sl in (slice(0, 3), slice(h // 2, h // 2 + 3), slice(h - 3, h)):       # first rows, the middle (past 2 GiB), the very end
+        ref = O.bias_act(x[:, :, sl].float().cpu(), b.float().cpu(), act="lrelu", clamp=1.5)
+        check(y[:, :, sl], ref, 2e-2)
+    del y
+    with pytest.raises(RuntimeError, match="too large"):
+        bias_act.bias_act(torch.empty([2 ** 31 + 8], dtype=torch.bfloat16, device=dev), act="relu")
+    del x
+    torch.cuda.empty_cache()
+    # empty batches
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+    assert upfirdn2d.upfirdn2d(torch.zeros([0, 8, 16, 16], device=dev), f, up=2, padding=1).shape[0] == 0
+    assert bias_act.bias_act(torch.zeros([0, 8, 4, 4], device=dev), torch.zeros(8, device=dev), act="lrelu").shape == (0, 8, 4, 4)
+    assert fma.fma(torch.zeros([0, 4, 2, 2], device=dev), torch.zeros([0, 4, 1, 1], device=dev), torch.zeros([0, 1, 2, 2], device=dev)).numel() == 0
