@@ -133,6 +133,21 @@ def _fold_passes(passes, x_cat_dim, w_cat_dim):
 # (a parameter is used by several forward / data-gradient launches between two optimizer steps).
 
 _pack_cache = {}
+_ptr_epoch = {}         # parameter storage -> number of optimizer steps that touched it
+
+
+def _on_optimizer_step(optimizer, args, kwargs):
+    """Fused optimizers (torch.optim.Adam(fused=True), ...) update parameters WITHOUT bumping their version counters, so the version alone
+    cannot validate a cached operand: every optimizer step also advances a per-parameter epoch (global post-step hook, any optimizer)."""
+    for group in optimizer.param_groups:
+        for q in group["params"]:
+            if isinstance(q, torch.Tensor) and q.device.type == "cuda":
+                k = q.data_ptr()
+                _ptr_epoch[k] = _ptr_epoch.get(k, 0) + 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook      # noqa: E402
+_register_step_hook(_on_optimizer_step)
 
 
 def is_mixed(x, w):
@@ -152,7 +167,8 @@ def _packed_weight(w, rows_dim, dtype, bp, gain):
     if cacheable:
         key = (base.data_ptr(), w.storage_offset(), tuple(w.shape), tuple(w.stride()), rows_dim, dtype, bp, float(gain))
         hit = _pack_cache.get(key)
-        if hit is not None and hit[0]() is base and hit[1] == base._version:
+        stamp = (base._version, _ptr_epoch.get(base.data_ptr(), 0))
+        if hit is not None and hit[0]() is base and hit[1] == stamp:
             return hit[2], hit[3]
     out = torch.empty([kh * kw, A, bp], dtype=dtype, device=w.device)
     w2 = torch.empty([A, B], dtype=torch.float32, device=w.device) if rows_dim == 0 else None
@@ -165,7 +181,7 @@ def _packed_weight(w, rows_dim, dtype, bp, gain):
                 del _pack_cache[k]
             if len(_pack_cache) > 2048:
                 _pack_cache.clear()
-        _pack_cache[key] = (weakref.ref(base), base._version, out, w2)
+        _pack_cache[key] = (weakref.ref(base), (base._version, _ptr_epoch.get(base.data_ptr(), 0)), out, w2)
     return out, w2
 
 

@@ -448,6 +448,16 @@ def test_master_weight_convolutions(dev):
         with torch.no_grad():
             w.mul_(2.0)
         assert torch.equal(fn(xb, w, stride=stride, padding=k // 2, wgain=gain), fn(xb, (w * gain).to(torch.bfloat16), stride=stride, padding=k // 2))
+    # fused optimizers update parameters without touching the version counter: the cache must still notice (per-parameter epoch)
+    w = torch.nn.Parameter(torch.randn(16, 16, 3, 3, device=dev))
+    xb = torch.randn(2, 16, 8, 8, device=dev).to(torch.bfloat16)
+    for fused in (True, False):
+        opt = torch.optim.Adam([w], lr=0.5, fused=fused)
+        y0 = conv2d_gradfix.conv2d(xb, w, padding=1)
+        w.grad = torch.randn_like(w)
+        opt.step()
+        y1 = conv2d_gradfix.conv2d(xb, w, padding=1)
+        assert torch.equal(y1, conv2d_gradfix.conv2d(xb, w.detach().to(torch.bfloat16), padding=1)) and not torch.equal(y0, y1)
     # double backward through the mixed path (what R1 does with the discriminator's convolutions)
     w = torch.nn.Parameter(torch.randn(8, 8, 3, 3, device=dev))
     xb = torch.randn(2, 8, 8, 8, device=dev).to(torch.bfloat16).requires_grad_(True)
