@@ -580,3 +580,34 @@ def test_maximum_sizes_and_empty_inputs(dev):
     assert upfirdn2d.upfirdn2d(torch.zeros([0, 8, 16, 16], device=dev), f, up=2, padding=1).shape[0] == 0
     assert bias_act.bias_act(torch.zeros([0, 8, 4, 4], device=dev), torch.zeros(8, device=dev), act="lrelu").shape == (0, 8, 4, 4)
     assert fma.fma(torch.zeros([0, 4, 2, 2], device=dev), torch.zeros([0, 4, 1, 1], device=dev), torch.zeros([0, 1, 2, 2], device=dev)).numel() == 0
+
+
+def test_separable_fused_kernel_against_two_passes(dev):
+    """sbg_upfirdn2d_separable (both passes of a rank-1 filter in one launch, planar fp32) against the oracle over tap counts 1..16,
+    up / down in {1, 2}, positive / negative / asymmetric padding, both flip settings, ragged image sizes; plus its gradient."""
+    torch.manual_seed(16)
+    cases = 0
+    for taps in (1, 2, 3, 5, 8, 12, 16):
+        f = torch.randn(taps)
+        for up, down in ((1, 1), (2, 1), (1, 2), (2, 2)):
+            for pad in (0, [taps // 2, (taps - 1) // 2, taps // 2, (taps - 1) // 2], [3, 1, 0, 2], [-1, 2, 1, -2]):
+                for flip in (False, True):
+                    n, c, h, w = 2, 3, 37, 70
+                    x = torch.randn(n, c, h, w)
+                    try:
+                        ref = O.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=1.7)
+                    except Exception:
+                        continue                              # configuration with an empty output
+                    if ref.numel() == 0:
+                        continue
+                    xg = x.to(dev).requires_grad_(True)
+                    y = upfirdn2d.upfirdn2d(xg, f.to(dev), up=up, down=down, padding=pad, flip_filter=flip, gain=1.7)
+                    check(y, ref, 1e-5)
+                    if taps in (3, 12) and flip is False:
+                        dy = torch.randn_like(ref)
+                        xr = x.clone().requires_grad_(True)
+                        gr, = torch.autograd.grad((O.upfirdn2d(xr, f, up=up, down=down, padding=pad, flip_filter=flip, gain=1.7) * dy).sum(), xr)
+                        gg, = torch.autograd.grad((y * dy.to(dev)).sum(), xg)
+                        check(gg, gr, 1e-5)
+                    cases += 1
+    assert cases > 150
