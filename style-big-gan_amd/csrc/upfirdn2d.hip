@@ -268,10 +268,10 @@ template <> struct FirMfma<f16_s> {
     static __device__ __forceinline__ short bits(float v) { return (short)f32_to_f16_bits(v); }
 };
 
-template <class T>
-__global__ __launch_bounds__(256, 2) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs p, unsigned x_bytes, int tiles_x, int tiles_y, int cblocks)
+template <class T, int RPW>      // RPW = output rows per wave: 2 (8 x 32 tile, 68 KB of LDS, 2 workgroups per CU) or 1 (4 x 32 tile, 43 KB, 3 per CU)
+__global__ __launch_bounds__(256, RPW == 1 ? 3 : (RPW == 2 ? 2 : 1)) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs p, unsigned x_bytes, int tiles_x, int tiles_y, int cblocks)
 {
-    constexpr int TY = 8, TX = 32, FH = 4, FW = 4;
+    constexpr int TY = 4 * RPW, TX = 32, FH = 4, FW = 4;
     constexpr int WY = TY + FH - 1;                    // 11 window rows
     constexpr int WXL = 48;                            // LDS row pitch in pixels: the K window of the second 16-pixel segment ends at 16 + 32
     constexpr int PPR = 5;                             // DMA pieces (8 pixels) per window row: pixels 0..39 (35 needed)
@@ -333,16 +333,16 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    float4_t acc[2][2][4];                               // [output row of this wave][16-pixel segment][16-channel block]
+    float4_t acc[RPW][2][4];                             // [output row of this wave][16-pixel segment][16-channel block]
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < RPW; a++)
 #pragma unroll
         for (int sg = 0; sg < 2; sg++)
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[a][sg][c] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int rl = 0; rl < 2 + FH - 1; rl++) {            // the five window rows behind this wave's two output rows
-        const unsigned char* rowp = fsm + ((2 * wave + rl) * WXL) * 128;
+    for (int rl = 0; rl < RPW + FH - 1; rl++) {          // the window rows behind this wave's output rows
+        const unsigned char* rowp = fsm + ((RPW * wave + rl) * WXL) * 128;
 #pragma unroll
         for (int sg = 0; sg < 2; sg++)
 #pragma unroll
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs 
                 const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fir_lds_s4_ptr)(q + 16 * 128));
                 const short8_t fa = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-                for (int a = 0; a < 2; a++) {
+                for (int a = 0; a < RPW; a++) {
                     const int ky = rl - a;
                     if (ky < 0 || ky >= FH) continue;
                     acc[a][sg][c] = FirMfma<T>::run(fa, bt[ky], acc[a][sg][c]);
@@ -375,8 +375,8 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs 
         if (p.tail && p.bias)   t_bias[c] = *reinterpret_cast<const float4_t*>(p.bias + ch);
     }
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-        const int oy = oy0 + 2 * wave + a;
+    for (int a = 0; a < RPW; a++) {
+        const int oy = oy0 + RPW * wave + a;
 #pragma unroll
         for (int sg = 0; sg < 2; sg++) {
             const int ox = ox0 + sg * 16 + fi;
@@ -407,16 +407,16 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_mfma_kernel(UpfirdnArgs 
     }
 }
 
-template <class T>
-static bool launch_fir_mfma(const UpfirdnArgs& a, hipStream_t stream)
+template <class T, int RPW>
+static bool launch_fir_mfma_rpw(const UpfirdnArgs& a, hipStream_t stream)
 {
-    constexpr int lds = 11 * 48 * 128;
+    constexpr int TY = 4 * RPW, lds = (TY + 3) * 48 * 128;
     const int64_t x_bytes = 2 * ((int64_t)(a.N - 1) * a.isn + (int64_t)(a.inH - 1) * a.isy + (int64_t)(a.inW - 1) * a.isx + a.C);
     if (x_bytes >= (int64_t)SBG_FIR_OOB || a.isn < 0 || a.isy < 0 || a.isx < 0) return false;
-    const int tiles_x = (a.outW + 31) / 32, tiles_y = (a.outH + 7) / 8, cblocks = a.C / 64;
+    const int tiles_x = (a.outW + 31) / 32, tiles_y = (a.outH + TY - 1) / TY, cblocks = a.C / 64;
     const int64_t nblk = (int64_t)a.N * tiles_y * tiles_x * cblocks;
     if (nblk > INT32_MAX || nblk <= 0) return false;
-    auto kern = upfirdn2d_fir_mfma_kernel<T>;
+    auto kern = upfirdn2d_fir_mfma_kernel<T, RPW>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
@@ -424,6 +424,15 @@ static bool launch_fir_mfma(const UpfirdnArgs& a, hipStream_t stream)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, tiles_y, cblocks);
     return true;
+}
+
+template <class T>
+static bool launch_fir_mfma(const UpfirdnArgs& a, hipStream_t stream)
+{
+    static const char* e = getenv("SBG_FIR_RPW");        // experiment switch: 1 = 4 x 32 tiles (3 workgroups per CU)
+    if (e && atoi(e) == 1) return launch_fir_mfma_rpw<T, 1>(a, stream);
+    if (e && atoi(e) == 4) return launch_fir_mfma_rpw<T, 4>(a, stream);
+    return launch_fir_mfma_rpw<T, 2>(a, stream);
 }
 
 template <class T> static bool try_fir_mfma(const UpfirdnArgs& a, hipStream_t stream) { return launch_fir_mfma<T>(a, stream); }
