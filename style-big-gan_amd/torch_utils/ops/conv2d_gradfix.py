@@ -150,6 +150,13 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _register
 _register_step_hook(_on_optimizer_step)
 
 
+def invalidate_packed_weights():
+    """Drop every cached operand.  The cache follows parameter updates through the tensor version counter (any in-place op, `copy_`,
+    `load_state_dict`, foreach optimizers) and the optimizer-step hook above (fused optimizers); writes that bypass both -- in-place ops on
+    `param.data`, raw pointer writes from other libraries -- must be followed by this call."""
+    _pack_cache.clear()
+
+
 def is_mixed(x, w):
     return w.dtype == torch.float32 and x.dtype in (torch.bfloat16, torch.float16)
 
