@@ -233,7 +233,7 @@ def main():
                 k = shapes.setdefault((r['kind'], r['dims']), [0, 0.0, 0.0, 0.0])
                 k[0] += 1; k[1] += r['ms']; k[2] += r['flops']; k[3] += r['bytes']
             print('top launches by total time (kind, dims): launches, ms/step, avg us, TFLOP/s, GB/s', file=sys.stderr)
-            for (kind, dims), (cnt, ms, fl, by) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
+            for (kind, dims), (cnt, ms, fl, by) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:90]:
                 print(f'  {kind:13s} {str(dims):52s} {cnt:5d} {ms / args.steps:8.3f} {ms / cnt * 1e3:9.1f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:8.1f}', file=sys.stderr)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

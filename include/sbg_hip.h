@@ -128,7 +128,8 @@ typedef struct sbg_conv_params {
     /* Optional split of the reduction (taps x channels) over `ksplit` workgroups per output tile, for launches with too few
      * output tiles to fill the chip (the 4x4 / 8x8 blocks): partial fp32 results go to `workspace`
      * (>= sbg_conv2d_igemm_workspace() bytes) and a second kernel sums them in a fixed order into y (bitwise reproducible).
-     * Needs a dense fp32 y without fused epilogue; ksplit <= 1 or workspace == NULL = off. */
+     * Needs a dense channel-minor y; a fused epilogue and a 16-bit output are applied by that second kernel (then without `accumulate`,
+     * Cout % 8 == 0); ksplit <= 1 or workspace == NULL = off. */
     void* workspace; int ksplit;
     /* Optional phases: nphase in 2..4 makes ONE launch compute several output sub-grids of the same input -- the s x s phases of a
      * stride-s transposed convolution, whose tiles then share the input through L2 instead of streaming it from HBM once per phase.

@@ -412,7 +412,7 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     SBG_CHECK(q->ntaps >= 1 && q->ntaps <= SBG_MAX_TAPS, "conv2d_igemm: 1..%d taps", SBG_MAX_TAPS);
     SBG_CHECK(q->stride >= 1, "conv2d_igemm: stride must be >= 1");
     SBG_CHECK(!q->accumulate || q->ydtype == SBG_F32, "conv2d_igemm: accumulate needs an fp32 output");
-    SBG_CHECK(q->ksplit <= 1 || (q->workspace != nullptr && q->ydtype == SBG_F32), "conv2d_igemm: ksplit > 1 needs a workspace and an fp32 output");
+    SBG_CHECK(q->ksplit <= 1 || q->workspace != nullptr, "conv2d_igemm: ksplit > 1 needs a workspace");
     SBG_CHECK(q->act == 0 || q->act == SBG_ACT_LINEAR || q->act == SBG_ACT_RELU || q->act == SBG_ACT_LRELU, "conv2d_igemm: fused activation must be linear, relu or lrelu");
     SBG_CHECK(sbg_aligned16(q->x) && sbg_aligned16(q->w), "conv2d_igemm: x and w must be 16-byte aligned");
     SBG_CHECK((q->xs_n % 8) == 0 && (q->xs_h % 8) == 0 && (q->xs_w % 8) == 0 && (q->ws_slab % 8) == 0 && (q->ws_co % 8) == 0,

@@ -948,6 +948,42 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* ws
     }
 }
 
+// Slab reduction with the fused epilogue: y[p][co] = clamp(act(sum_k ws[k][p][co] * oscale[n, co] + noise[n, pixel] + bias[co]) * gain), any output
+// dtype, dense channel-minor y.  Lets the few-tile / long-K launches of the 16-bit 4x4 .. 8x8 blocks (16-64 workgroups for 72 K-steps) split K as
+// well: 8 channels per lane, 16-B loads per slab.
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_epi_kernel(const float* ws, ConvArgs p, int64_t n, int ksplit)
+{
+    const int64_t groups = n >> 3;                      // n = P * Cout, Cout % 8 == 0
+    const int hw = p.OH * p.OW;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+        const int64_t i = g << 3;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < ksplit; k++) {
+            float v[8];
+            Vec8<float>::ld(ws + (int64_t)k * n + i, v);
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += v[e];
+        }
+        const int64_t pix = i / p.Cout; const int co = (int)(i - pix * p.Cout);
+        const int img = (int)(pix / hw), pp = (int)(pix - (int64_t)img * hw);
+        const float nz = p.noise ? p.noise[(int64_t)img * p.noise_sn + pp] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float u = acc[e];
+            if (p.oscale) u *= p.oscale[(int64_t)img * p.Cout + co + e];
+            u += nz + (p.bias ? p.bias[co + e] : 0.f);
+            if (p.act == SBG_ACT_LRELU) u = (u > 0.f) ? u : u * p.alpha;
+            else if (p.act == SBG_ACT_RELU) u = (u > 0.f) ? u : 0.f;
+            u *= p.gain;
+            if (p.clamp >= 0.f) u = (u > -p.clamp && u < p.clamp) ? u : (u >= 0.f ? p.clamp : -p.clamp);
+            acc[e] = u;
+        }
+        if (p.ydtype == SBG_F32)       Vec8<float>::st((float*)p.y + i, acc);
+        else if (p.ydtype == SBG_BF16) Vec8<bf16_s>::st((bf16_s*)p.y + i, acc);
+        else                           Vec8<f16_s>::st((f16_s*)p.y + i, acc);
+    }
+}
+
 template <class MF>
 static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStream_t stream)
 {
@@ -1004,15 +1040,23 @@ int sbg_conv_k64_dispatch(ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_byt
     const int64_t y_numel = (int64_t)a.P * a.Cout;
     const bool dense_y = a.ys_w == a.Cout && a.ys_h == (int64_t)a.OW * a.Cout && a.ys_n == (int64_t)a.OH * a.OW * a.Cout;
     const bool plain = (a.act <= SBG_ACT_LINEAR) && a.gain == 1.f && a.clamp < 0.f && !a.bias && !a.noise && !a.oscale;
-    const int k = (workspace && a.ydtype == SBG_F32 && dense_y && plain) ? plan_ksplit(a, ksplit) : 1;
+    const bool simple = a.ydtype == SBG_F32 && plain;                      // plain fp32 sum (may accumulate); otherwise the epilogue rides in the reduction
+    const bool epi_ok = !a.accumulate && (a.Cout & 7) == 0 && (((uintptr_t)a.y) & 15) == 0;
+    const int k = (workspace && dense_y && (simple || epi_ok)) ? plan_ksplit(a, ksplit) : 1;
     if (k > 1) {
         ConvArgs b = a;
         void* y = a.y; const int acc = a.accumulate;
         b.y = workspace; b.accumulate = 0; b.ksplit = k; b.y_split_stride = y_numel;
+        b.ydtype = SBG_F32; b.act = SBG_ACT_LINEAR; b.gain = 1.f; b.clamp = -1.f; b.bias = nullptr; b.noise = nullptr; b.oscale = nullptr;    // raw fp32 slabs
         const int rc = bf16 ? dispatch_k64<bf16_mfma>(b, level, xb, wb, stream) : dispatch_k64<f16_mfma>(b, level, xb, wb, stream);
         if (rc != SBG_OK) return rc;
-        unsigned grid = (unsigned)((y_numel + 15) / 16); if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)workspace, (float*)y, y_numel, k, acc);
+        if (simple) {
+            unsigned grid = (unsigned)((y_numel + 15) / 16); if (grid > 4096) grid = 4096;
+            hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)workspace, (float*)y, y_numel, k, acc);
+        } else {
+            unsigned grid = (unsigned)((y_numel / 8 + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+            hipLaunchKernelGGL(conv_ksplit_reduce_epi_kernel, dim3(grid), dim3(256), 0, stream, (const float*)workspace, a, y_numel, k);
+        }
         SBG_HIP_LAUNCH_CHECK();
         return SBG_OK;
     }

@@ -231,12 +231,13 @@ def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=N
     if epi is not None:
         assert not accumulate and y_step == (1, 1)
         epi.fill(p, n, cout, oh, ow)
-    # few output tiles but a long reduction (the 4x4 / 8x8 fp32 blocks: 16 tiles x 432 K-steps): split K over workgroups
+    # few output tiles but a long reduction (the 4x4 fp32 block: 16 tiles x 432 K-steps; the 16-bit 4x4 .. 8x8 layers: 16-64 tiles x 72): split K over
+    # workgroups; the fixed-order slab reduction applies the fused epilogue and the output cast
     ws = None
     tiles = -(-(n * oh * ow) // 128) * -(-cout // 128)
     ksteps = len(taps) * -(-cin // 64)
-    if (epi is None and y.dtype == torch.float32 and y_step == (1, 1) and y_off == (0, 0) and cout > 64 and tiles < 128 and ksteps >= 16
-            and y.is_contiguous(memory_format=torch.channels_last)):
+    if ((epi is None or not accumulate) and (y.dtype == torch.float32 or not accumulate) and y_step == (1, 1) and y_off == (0, 0) and cout > 64
+            and cout % 8 == 0 and tiles < 128 and ksteps >= 16 and y.is_contiguous(memory_format=torch.channels_last)):
         p.ksplit = max(1, min(ksteps // 4, -(-256 // tiles)))
         if p.ksplit > 1:
             ws = torch.empty([lib.sbg_conv2d_igemm_workspace(p) // 4], dtype=torch.float32, device=x.device)

@@ -229,6 +229,17 @@ def test_conv2d_split_k(dev):
     _conv_case(dev, torch.float32, 8, 512, 520, 4, 4, 3, 1, 1, False)        # the 4x4 block: 6 folded passes -> K = 9 x 3072
     _conv_case(dev, torch.float32, 2, 264, 136, 8, 8, 3, 1, 1, False)
     _conv_case(dev, torch.float32, 4, 128, 128, 4, 4, 3, 2, 0, True)         # transposed phases write strided outputs: no split
+    # 16-bit outputs and fused epilogues split too (the slab reduction applies the epilogue and the cast)
+    _conv_case(dev, torch.bfloat16, 8, 512, 512, 8, 8, 3, 1, 1, False)
+    _conv_case(dev, torch.bfloat16, 8, 512, 256, 8, 8, 3, 2, 1, False)
+    from style_big_gan_amd.torch_utils.ops import conv_bias_act
+    torch.manual_seed(21)
+    xq = torch.randn(4, 512, 8, 8).to(torch.bfloat16).float(); wq = (torch.randn(136, 512, 3, 3) / 70).to(torch.bfloat16).float(); bq = torch.randn(136).to(torch.bfloat16).float()
+    for act, clamp in (("lrelu", 1.0), ("linear", None), ("relu", 0.3)):
+        ref = O.bias_act(torch.nn.functional.conv2d(xq, wq, padding=1), bq, act=act, clamp=clamp)
+        got = conv_bias_act.conv2d_bias_act(xq.to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last), wq.to(dev, torch.bfloat16),
+                                            bq.to(dev, torch.bfloat16), padding=1, act=act, clamp=clamp)
+        check(got, ref, 2e-2, f"split-K conv + fused {act}")
 
 
 def test_conv2d_large_k_and_many_pixels(dev):
