@@ -145,20 +145,51 @@ def _launch_separable(x, f, up, down, padx0, padx1, pady0, pady1, flip, gain):
     return y
 
 
-_exact_cache = {}
+import weakref
+
+_filter_facts = {}      # id(filter tensor) -> [weakref, version, sightings, {fact: value}]
+
+
+def _filter_fact(f, name, compute, default, eager=False):
+    """Cached property of a filter tensor that needs a device -> host read to establish.  Keyed on the tensor OBJECT (weak reference +
+    version counter: a recycled id or an in-place edit starts over), not on its address -- the allocator hands the address of a dead
+    temporary to the next one.  Unless `eager`, the read is made from the second sighting of an object on (module buffers); a filter built
+    on the fly is a new object every call and gets `default` (the conservative path) without synchronising."""
+    e = _filter_facts.get(id(f))
+    if e is None or e[0]() is not f or e[1] != f._version:
+        if len(_filter_facts) > 1024:
+            for k in [k for k, v in _filter_facts.items() if v[0]() is None]:
+                del _filter_facts[k]
+        e = _filter_facts[id(f)] = [weakref.ref(f), f._version, 1, {}]
+        if not eager:
+            return default
+    if name not in e[3]:
+        e[3][name] = compute(f)
+    return e[3][name]
 
 
 def _taps_exact(f, dtype):
-    """are all taps of f exactly representable in `dtype`?  (the matrix-core FIR path takes the filter in the tensor dtype.)  One device
-    -> host read per filter tensor and version, cached; filters are module buffers that never change during training."""
-    key = (f.data_ptr(), f._version, tuple(f.shape), tuple(f.stride()), dtype)
-    hit = _exact_cache.get(key)
-    if hit is None:
-        if len(_exact_cache) > 256:
-            _exact_cache.clear()
-        hit = bool((f.to(dtype).to(torch.float32) == f).all().item())
-        _exact_cache[key] = hit
-    return hit
+    """are all taps of f exactly representable in `dtype`?  (the matrix-core FIR path takes the filter in the tensor dtype.)"""
+    # eager: asked only for 4x4 filters of 16-bit up = down = 1 launches (the resampling low-pass, a module buffer)
+    return _filter_fact(f, ("exact", dtype), lambda t: bool((t.to(dtype).to(torch.float32) == t).all().item()), False, eager=True)
+
+
+def _rank1_factor(f):
+    """f [k, k] == outer(g, g)?  -> g (float32, on f's device) or None.  The reference keeps short filters 2-D (`setup_filter`: separable only
+    from 8 taps, upfirdn2d.py:98-100), but [1, 3, 3, 1] x [1, 3, 3, 1] is an outer product: the planar fp32 launches (the RGB skip branch) can
+    then take the fused separable kernel."""
+    def compute(t):
+        if t.ndim != 2 or t.shape[0] != t.shape[1] or t.shape[0] < 2:
+            return None
+        h = t.detach().to("cpu", torch.float64)
+        j = int(torch.argmax(h.diagonal().abs()))
+        if float(h[j, j]) <= 0:
+            return None
+        cand = h[:, j] / h[j, j].sqrt()
+        if float((torch.outer(cand, cand) - h).abs().max()) > 1e-7 * float(h.abs().max()):
+            return None
+        return cand.to(torch.float32).to(t.device)
+    return _filter_fact(f, "rank1", compute, None)
 
 
 class _Upfirdn2d(torch.autograd.Function):
@@ -170,7 +201,12 @@ class _Upfirdn2d(torch.autograd.Function):
         if f is None:
             f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
         assert f.ndim in [1, 2]
-        if f.ndim == 2:
+        g1 = None
+        if f.ndim == 2 and x.dtype == torch.float32 and x.is_contiguous() and upx == upy and downx == downy and (upx > 1 or downx > 1):
+            g1 = _rank1_factor(f)
+        if g1 is not None and _separable_fused_ok(x, g1, upx, upy, downx, downy):
+            y = _launch_separable(x, g1, upx, downx, padx0, padx1, pady0, pady1, flip, gain)
+        elif f.ndim == 2:
             y = _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
         elif _separable_fused_ok(x, f, upx, upy, downx, downy):
             y = _launch_separable(x, f, upx, downx, padx0, padx1, pady0, pady1, flip, gain)
