@@ -392,7 +392,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
 }
 
 static void plan_split_target(WgradArgs& a, int bca, int bcb, int target);
-static void plan_split(WgradArgs& a, int bca, int bcb) { plan_split_target(a, bca, bcb, 1024); }
+static void plan_split(WgradArgs& a, int bca, int bcb)
+{
+    static const char* e = getenv("SBG_WGRAD_TARGET");      // experiment switch: workgroups aimed for (tiles x pixel splits)
+    plan_split_target(a, bca, bcb, e ? atoi(e) : 1024);
+}
 static void plan_split_target(WgradArgs& a, int bca, int bcb, int target)
 {
     a.atiles = (a.Ca + bca - 1) / bca;
