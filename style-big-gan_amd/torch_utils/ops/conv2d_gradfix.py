@@ -112,6 +112,10 @@ class Epilogue:
         p.act, p.alpha, p.gain, p.clamp = self.act, self.alpha, self.gain, self.clamp
 
 
+import os as _os
+_KSPLIT_MAX_TILES = int(_os.environ.get('SBG_KSPLIT_MAX_TILES', '128'))     # experiment switches for the K split of few-tile launches
+_KSPLIT_TARGET = int(_os.environ.get('SBG_KSPLIT_TARGET', '256'))
+
 CONCAT_NUMEL = 1 << 22      # fp32 operands up to this many elements: fold the split passes into ONE launch (see _fold_passes)
 
 
@@ -237,8 +241,8 @@ def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=N
     tiles = -(-(n * oh * ow) // 128) * -(-cout // 128)
     ksteps = len(taps) * -(-cin // 64)
     if ((epi is None or not accumulate) and (y.dtype == torch.float32 or not accumulate) and y_step == (1, 1) and y_off == (0, 0) and cout > 64
-            and cout % 8 == 0 and tiles < 128 and ksteps >= 16 and y.is_contiguous(memory_format=torch.channels_last)):
-        p.ksplit = max(1, min(ksteps // 4, -(-256 // tiles)))
+            and cout % 8 == 0 and tiles < _KSPLIT_MAX_TILES and ksteps >= 16 and y.is_contiguous(memory_format=torch.channels_last)):
+        p.ksplit = max(1, min(ksteps // 4, -(-_KSPLIT_TARGET // tiles)))
         if p.ksplit > 1:
             ws = torch.empty([lib.sbg_conv2d_igemm_workspace(p) // 4], dtype=torch.float32, device=x.device)
             p.workspace = ws.data_ptr()
