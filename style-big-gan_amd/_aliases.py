@@ -12,6 +12,8 @@ _MAP = {
     "stylegan2ada.torch_utils.ops.grid_sample_gradfix": "torch_utils.ops.grid_sample_gradfix",
     "stylegan2ada.training.augment": "train_parts.augmentations",
     "train_parts.augmentations": "train_parts.augmentations",
+    "train_parts.datasets": "train_parts.datasets",
+    "train_parts.dataloaders": "train_parts.dataloaders",
     "stylegan2ada.torch_utils.misc": "torch_utils.misc",
     "stylegan2ada.torch_utils.training_stats": "torch_utils.training_stats",
     "train_parts.generators": "train_parts.generators",

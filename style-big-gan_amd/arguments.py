@@ -6,7 +6,7 @@ losses_arch_args, gen_regs_all, disc_regs_all`` -- :112-143, each holding one kw
 from its ``__init__`` signature), and the same precedence as ``load_config`` (:146-159), so the reference's ``configs/*.yaml``
 and ``key.sub=value`` overrides (Readme.md:28-30) load unchanged.  The reference builds this on OmegaConf; that package is
 optional here -- this module is a small yaml + dot-list implementation of the same contract.  Groups for components that are
-out of scope (datasets, dataloaders) are accepted and carried verbatim.
+out of scope are accepted and carried verbatim.
 """
 import copy
 import dataclasses
@@ -66,8 +66,10 @@ def _register_model_groups():
     args.classes["disc_regs_all"] = _registry_group(discriminator_regs)
     from .train_parts.augmentations import augmentations
     args.classes["augpipe_specs"] = _registry_group(augmentations)
-    for passthrough in ("datasets_args", "dataloaders_args"):
-        args.classes[passthrough] = lambda: EasyDict()
+    from .train_parts.datasets import datasets
+    from .train_parts.dataloaders import dataloaders
+    args.classes["datasets_args"] = _registry_group(datasets)
+    args.classes["dataloaders_args"] = _registry_group(dataloaders)
 
 
 def structured_defaults():

@@ -245,9 +245,11 @@ class BaseTrainer:
         if gen.batch % gpus != 0 or gen.batch % (gpus * batch_gpu) != 0:
             raise ValueError("gen.batch must be a multiple of perf.gpus * gen.batch_gpu")
         self.aug = self._augment_arguments(config)
-        if config.data.dataset != "synthetic":
-            raise NotImplementedError("dataset loading is outside this build's hot path: run with data.dataset=synthetic "
-                                      "(data.resolution=<R> data.num_classes=<K>)")
+        self.real_data = config.data.dataset != "synthetic"
+        if self.real_data:
+            from .datasets import datasets
+            if config.data.dataset not in datasets:
+                raise ValueError(f"data.dataset={config.data.dataset}: use 'synthetic' (data.resolution=<R> data.num_classes=<K>) or one of {sorted(datasets.classes)}")
         self.resume_path = None if config.trans.resume == "noresume" else str(config.trans.resume)     # a network-snapshot-*.pt of this build
         if self.resume_path is not None and not os.path.isfile(self.resume_path):
             raise ValueError(f"trans.resume={self.resume_path}: no such snapshot file (named transfer-learning sources are URL fetches and "
@@ -256,8 +258,31 @@ class BaseTrainer:
         self.snapshot_iterations = None     # iterations between snapshots; None = only on request
         self.config = config
         self.num_gpus, self.batch_size, self.batch_gpu = gpus, gen.batch, batch_gpu
-        self.dataset = SyntheticDataset(int(config.data.get("resolution", 32)), 3,
-                                        int(config.data.get("num_classes", 0)) if config.data.cond else 0, seed=gen.seed)
+        if self.real_data:      # reference :230-261: probe the data once, then be explicit about resolution / labels / size
+            from .datasets import datasets
+            kw = {k: v for k, v in dict(config.get("datasets_args", {}).get(config.data.dataset, {})).items() if k not in ("args", "kwargs") and v != utils.MISSING}
+            kw["path"] = config.data.dataset_path
+            probe = datasets[config.data.dataset](**kw)
+            kw.update(resolution=probe.resolution, use_labels=probe.has_labels, max_size=len(probe))
+            if config.data.cond and not kw["use_labels"]:
+                raise ValueError("data.cond=true requires labels specified in dataset.json")
+            if not config.data.cond:
+                kw["use_labels"] = False
+            if config.data.subset:
+                if not 1 <= config.data.subset <= kw["max_size"]:
+                    raise ValueError(f"data.subset must be between 1 and {kw['max_size']}")
+                if config.data.subset < kw["max_size"]:
+                    kw.update(max_size=int(config.data.subset), random_seed=gen.seed)
+            if config.data.mirror:
+                kw["xflip"] = True
+            probe.close()
+            self.training_set_kwargs = kw
+            self.data_loader_kwargs = {k: v for k, v in dict(config.get("dataloaders_args", {}).get(config.data.dataloader, {})).items()
+                                       if k not in ("args", "kwargs") and v != utils.MISSING}
+            self.dataset = datasets[config.data.dataset](**kw)
+        else:
+            self.dataset = SyntheticDataset(int(config.data.get("resolution", 32)), 3,
+                                            int(config.data.get("num_classes", 0)) if config.data.cond else 0, seed=gen.seed)
         common = dict(c_dim=self.dataset.label_dim, img_resolution=self.dataset.resolution, img_channels=self.dataset.num_channels)
         self.G_kwargs = self._model_kwargs(config.gens_args[gen.generator], common)
         self.D_kwargs = self._model_kwargs(config.discs_args[gen.discriminator], common)
@@ -336,7 +361,21 @@ class BaseTrainer:
         torch.manual_seed(seed * self.num_gpus + self.rank)
 
     def setup_dataset(self):
-        pass        # synthetic batches are drawn on demand
+        """real data: endless rank-sharded stream of uint8 batches (reference :517-524); synthetic batches are drawn on demand"""
+        self.training_set_iterator = None
+        if self.real_data:
+            from .dataloaders import dataloaders
+            sampler = misc.InfiniteSampler(dataset=self.dataset, rank=self.rank, num_replicas=self.num_gpus, seed=self.config.gen.seed)
+            loader = dataloaders[self.config.data.dataloader](dataset=self.dataset, sampler=sampler, batch_size=self.batch_size // self.num_gpus,
+                                                              **self.data_loader_kwargs)
+            self.training_set_iterator = iter(loader)
+
+    def next_batch(self, n, device):
+        """-> (uint8 images [n, C, H, W], float32 labels [n, label_dim]) on `device` (normalisation happens there)"""
+        if self.training_set_iterator is None:
+            return self.dataset.batch(n, device)
+        img, c = next(self.training_set_iterator)
+        return img.to(device, non_blocking=True), c.to(device, non_blocking=True)
 
     def setup_networks(self):
         gen = self.config.gen
@@ -398,7 +437,7 @@ class BaseTrainer:
         total = self.total_kimg * 1000
         it = 0
         while (max_iterations is None or it < max_iterations) and (total < 0 or eng.cur_nimg < total or it == 0):
-            img, c = self.dataset.batch(eng.batch, eng.device)
+            img, c = self.next_batch(eng.batch, eng.device)
             eng.train_iteration(img.to(torch.float32) / 127.5 - 1, c)
             it += 1
             if self.snapshot_iterations and it % self.snapshot_iterations == 0:

@@ -67,7 +67,7 @@ def test_trainer_validation(tmp_path):
     from style_big_gan_amd.train_parts.trainers import trainers
     argv = _write(tmp_path, "sg2ada.yaml", SG2ADA_LIKE)
     cfg = arguments.load_config(argv)
-    with pytest.raises(NotImplementedError, match="synthetic"):   # dataset loading is out of scope; must be switched explicitly
+    with pytest.raises(IOError):                                  # data.dataset=image_folder with a path that does not exist
         trainers["sg2"]().setup_arguments(cfg)
     ada = trainers["sg2"]().setup_arguments(arguments.load_config(argv + ["data.dataset=synthetic", "data.resolution=64"])).aug
     assert ada["ada_target"] == 0.6 and ada["augment_p"] == 0.0 and ada["ada_interval"] == 4 and ada["augment_kwargs"]["hue"] == 1
@@ -123,3 +123,72 @@ def test_snapshot_and_resume(tmp_path):
     assert b.engine.batch_idx == 3 and b.engine.cur_nimg == 48
     with pytest.raises(ValueError):
         starter.main(argv + ["trans.resume=/nonexistent/file.pt"], max_iterations=1)
+
+
+def _make_image_folder(root, n=12, res=32, labels=True, as_zip=False):
+    import json, zipfile
+    import numpy as np
+    import PIL.Image
+    rng = np.random.RandomState(0)
+    os.makedirs(root / "00000", exist_ok=True)
+    names, arrays = [], []
+    for i in range(n):
+        a = rng.randint(0, 256, [res, res, 3], dtype=np.uint8)
+        name = f"00000/img{i:05d}.png"
+        PIL.Image.fromarray(a).save(root / name)
+        names.append(name); arrays.append(a)
+    if labels:
+        json.dump({"labels": [[nm, i % 3] for i, nm in enumerate(names)]}, open(root / "dataset.json", "w"))
+    if as_zip:
+        zp = str(root) + ".zip"
+        with zipfile.ZipFile(zp, "w") as z:
+            for nm in names + (["dataset.json"] if labels else []):
+                z.write(root / nm, nm)
+        return zp, arrays
+    return str(root), arrays
+
+
+def test_image_folder_dataset_and_sampler(tmp_path):
+    """directory and zip sources, labels from dataset.json (one-hot), max_size subset, x-flip doubling, rank-sharded endless sampler, loader"""
+    import numpy as np
+    from style_big_gan_amd.torch_utils import misc
+    from style_big_gan_amd.train_parts.dataloaders import dataloaders
+    from style_big_gan_amd.train_parts.datasets import datasets
+    path, arrays = _make_image_folder(tmp_path / "data")
+    zpath, _ = _make_image_folder(tmp_path / "dataz", as_zip=True)
+    for src in (path, zpath):
+        ds = datasets["image_folder"](path=src, use_labels=True)
+        assert len(ds) == 12 and ds.image_shape == [3, 32, 32] and ds.resolution == 32 and ds.num_channels == 3
+        assert ds.has_labels and ds.has_onehot_labels and ds.label_dim == 3 and ds.label_shape == [3]
+        img, lab = ds[4]
+        assert img.dtype == np.uint8 and np.array_equal(img, arrays[4].transpose(2, 0, 1)) and lab.tolist() == [0.0, 1.0, 0.0]
+        assert ds.get_details(4).raw_idx == 4 and not ds.get_details(4).xflip
+        ds.close()
+    nolab = datasets["image_folder"](path=path)
+    assert not nolab.has_labels and nolab.label_dim == 0 and nolab[0][1].shape == (0,)
+    sub = datasets["image_folder"](path=path, max_size=5, xflip=True, random_seed=3)
+    assert len(sub) == 10 and np.array_equal(sub[7][0], sub[2][0][:, :, ::-1]) and sub.get_details(7).xflip
+    with pytest.raises(IOError):
+        datasets["image_folder"](path=path, resolution=64)
+    with pytest.raises(IOError):
+        datasets["image_folder"](path=str(tmp_path / "missing"))
+    # sampler: two ranks see disjoint, jointly exhaustive index streams over a period
+    streams = []
+    for rank in range(2):
+        it = iter(misc.InfiniteSampler(nolab, rank=rank, num_replicas=2, seed=1, window_size=0))
+        streams.append([int(next(it)) for _ in range(6)])
+    assert sorted(streams[0] + streams[1]) == list(range(12))
+    loader = dataloaders["basic"](dataset=sub, sampler=misc.InfiniteSampler(sub, seed=0), batch_size=4, num_workers=0)
+    imgs, labs = next(iter(loader))
+    assert imgs.dtype == torch.uint8 and tuple(imgs.shape) == (4, 3, 32, 32) and tuple(labs.shape) == (4, 0)
+
+
+def test_training_on_an_image_folder(tmp_path):
+    if torch.cuda.is_available():
+        pytest.skip("plumbing test is for the CPU container")
+    path, _ = _make_image_folder(tmp_path / "data", n=20)
+    argv = _write(tmp_path, "dcgan.yaml", DCGAN_LIKE) + ["gen.batch=8", "gen.batch_gpu=8", "data.dataset=image_folder", f"data.dataset_path={path}",
+                                                         "data.mirror=true", "dataloaders_args.basic.num_workers=0", "gen.kimg=1"]
+    t = starter.main(argv, max_iterations=2)
+    assert t.engine.batch_idx == 2 and len(t.dataset) == 40 and t.dataset.resolution == 32 and t.training_set_kwargs["xflip"] is True
+    assert all(torch.isfinite(p).all() for p in t.engine.G.parameters())
