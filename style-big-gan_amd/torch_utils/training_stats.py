@@ -15,6 +15,7 @@ _DTYPE = torch.float64
 
 _rank = 0
 _sync_device = None
+_taps = dict()          # name -> [callables]: observers that see every reported tensor of that name (device-side consumers)
 _pending = dict()       # name -> device -> float64[3] accumulated since the last _sync
 _cumulative = dict()    # name -> float64[3] on CPU, all ranks, since start
 
@@ -25,12 +26,26 @@ def init_multiprocessing(rank, sync_device):
     _rank, _sync_device = rank, sync_device
 
 
+def add_tap(name, fn):
+    """fn(tensor) is called with every non-empty tensor reported under `name` (detached, on its device) -- for consumers that must
+    not wait for a Collector's host synchronisation (the ADA heuristic keeps its running sums on the device)."""
+    _taps.setdefault(name, []).append(fn)
+    return fn
+
+
+def remove_tap(name, fn):
+    if fn in _taps.get(name, []):
+        _taps[name].remove(fn)
+
+
 def report(name, value):
     """Accumulate `value` (scalar, tensor or array of any shape) under `name`; returns `value` unchanged."""
     slot = _pending.setdefault(name, dict())
     v = torch.as_tensor(value)
     if v.numel() == 0:
         return value
+    for fn in _taps.get(name, ()):
+        fn(v.detach())
     # The reference reduces every reported tensor to its three moments on the spot (eight launches of a few numbers each, ~20 reports per
     # iteration).  Here the (small) tensor is parked and the moments are formed once per name when a Collector asks for them.
     v = v.detach().flatten()

@@ -149,9 +149,26 @@ class AugmentPipe(torch.nn.Module):
 
     # -- strength mirror ---------------------------------------------------------------------------------------------
     def _strength(self):
+        """Host copy of `p`.  Default: read when the buffer's version changed (one synchronising read per ADA adjustment).  With
+        `async_strength` (set by StepEngine, whose heuristic updates `p` on the device) the new value is fetched by an asynchronous
+        copy into pinned memory and adopted once that copy has completed: the sampler may use the previous strength for an
+        iteration (the heuristic moves p by ~5e-4 per adjustment), and the host never waits for the device."""
         key = (self.p.data_ptr(), self.p._version)
         if self._p_cache[:2] != key:
-            self._p_cache = key + (float(self.p),)      # the only host read of the pipe; happens when `p` was written
+            if getattr(self, "async_strength", False) and self.p.device.type == "cuda" and self._p_cache[0] is not None:
+                pinned = torch.empty([], dtype=self.p.dtype, pin_memory=True)
+                pinned.copy_(self.p.detach(), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.p.device))
+                self._p_pending = (pinned, ev)
+                self._p_cache = key + (self._p_cache[2],)
+            else:
+                self._p_pending = None
+                self._p_cache = key + (float(self.p),)      # synchronising read
+        pend = getattr(self, "_p_pending", None)
+        if pend is not None and pend[1].query():
+            self._p_cache = self._p_cache[:2] + (float(pend[0]),)
+            self._p_pending = None
         return self._p_cache[2]
 
     # -- parameters --------------------------------------------------------------------------------------------------

@@ -88,7 +88,19 @@ class StepEngine:
             self.augment_pipe = augmentations[augment_type](**augment_kwargs).train().requires_grad_(False).to(self.device)
             self.augment_pipe.p.copy_(torch.as_tensor(float(augment_p)))
             if ada_target is not None:
-                self.ada_stats = training_stats.Collector(regex='Loss/signs/real')
+                self.ada_stats = training_stats.Collector(regex='Loss/signs/real')        # kept for reporting parity (reference :584)
+                # The reference reads E[sign(D(real))] through that collector: a host synchronisation every `ada_interval` iterations
+                # that drains the launch queue.  Here the running [count, sum] of the reported signs stays on the device and the
+                # adjustment of `p` is computed there; SBG_ADA_SYNC=1 restores the synchronous path.
+                self._ada_sync = os.environ.get('SBG_ADA_SYNC', '0') == '1' or self.device.type != 'cuda'
+                if not self._ada_sync:
+                    self._ada_acc = torch.zeros([2], dtype=torch.float64, device=self.device)
+                    def tap(v, acc=self._ada_acc):
+                        if v.device == acc.device:
+                            acc.add_(torch.stack([torch.full([], float(v.numel()), dtype=torch.float64, device=v.device), v.sum(dtype=torch.float64)]))
+                    self._ada_tap = training_stats.add_tap('Loss/signs/real', tap)
+                    self.augment_pipe._strength()               # one synchronising read of the initial strength, then lag-tolerant updates
+                    self.augment_pipe.async_strength = True
             la['augment_pipe'] = self.augment_pipe
         # the fused training-time synthesis layer is first order only: generator regularisers (path length) differentiate twice
         from ..torch_utils.ops import modconv
@@ -150,9 +162,19 @@ class StepEngine:
 
         # ADA heuristic (reference :768-771): nudge the strength so that E[sign(D(real))] tracks `ada_target`
         if self.ada_stats is not None and self.batch_idx % self.ada_interval == 0:
-            self.ada_stats.update()
-            adjust = np.sign(self.ada_stats['Loss/signs/real'] - self.ada_target) * (self.batch * self.world_size * self.ada_interval) / (self.ada_kimg * 1000)
-            self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp_(min=0))
+            step = (self.batch * self.world_size * self.ada_interval) / (self.ada_kimg * 1000)
+            if self._ada_sync:
+                self.ada_stats.update()
+                adjust = np.sign(self.ada_stats['Loss/signs/real'] - self.ada_target) * step
+                self.augment_pipe.p.copy_((self.augment_pipe.p + adjust).clamp_(min=0))
+            else:
+                acc = self._ada_acc
+                if self.world_size > 1:
+                    torch.distributed.all_reduce(acc)
+                mean = acc[1] / acc[0].clamp(min=1)
+                adjust = torch.where(acc[0] > 0, torch.sign(mean - self.ada_target) * step, torch.zeros_like(mean))
+                self.augment_pipe.p.copy_((self.augment_pipe.p + adjust.to(self.augment_pipe.p.dtype)).clamp_(min=0))
+                acc.zero_()
 
     # -- snapshot / resume (reference trainers.py:636-656 pickles whole modules; here plain state dicts + counters) ---------
     def state_dict(self):
