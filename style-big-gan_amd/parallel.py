@@ -11,9 +11,17 @@ the next backward synchronises" latch -- with an MI355X-oriented mechanism:
 * a post-accumulate-grad hook marks parameters ready; the moment a bucket's last gradient of a synchronising backward is
   written, ONE asynchronous ``all_reduce`` of the whole bucket is enqueued on RCCL's stream, so the exchange of the layers
   that finish backward first overlaps the backward of the rest;
-* ``finish()`` waits, averages and applies ``nan_to_num`` (the reference's per-parameter loop, trainers.py:745-747) over the
-  flat buckets -- a handful of launches instead of hundreds;
+* ``finish()`` ends a phase: every bucket that still holds un-exchanged gradients is reduced, then waited for, averaged and
+  passed through ``nan_to_num`` (the reference's per-parameter loop, trainers.py:745-747) over the flat buckets -- a handful
+  of launches instead of hundreds;
 * ``zero_grad()`` is one memset per bucket.
+
+Several synchronising backwards between ``zero_grad()`` and ``finish()`` (path-length or gradient-penalty regularisers run one
+per accumulation round; a phase with two regularisers runs two per round) are legal, as they are under DDP: a bucket keeps
+the invariant ``flat = mean over ranks of what was exchanged so far + this rank's gradients since``.  A forward through the
+wrapper first *settles* whatever an earlier backward left in flight (wait, scale by 1/world) so that the next backward never
+accumulates into a buffer RCCL is still reducing; the next exchange then sums ``mean_so_far + local_new`` over the ranks and
+the 1/world scaling gives ``mean_so_far + mean_new``.
 
 With ``world_size == 1`` nothing is communicated and the class is just the flat-gradient container.  The collective backend
 is whatever ``torch.distributed`` was initialised with: ``nccl`` (= RCCL) on GPUs, ``gloo`` in the CPU tests.
@@ -25,10 +33,11 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "ready", "work")
+    __slots__ = ("flat", "params", "ready", "work", "dirty")
 
     def __init__(self, flat, params):
         self.flat, self.params, self.ready, self.work = flat, params, set(), None
+        self.dirty = False          # holds gradients of this rank that no exchange has covered yet
 
 
 def _grad_view(flat, off, p):
@@ -86,6 +95,7 @@ class GradReducer(torch.nn.Module):
     # -- module passthrough -----------------------------------------------------------------------------------------
     def forward(self, *args, **kwargs):
         self._armed = self._sync_enabled
+        self._settle()              # an earlier backward of this phase may still be on the wire: complete it before the next one accumulates
         return self.module(*args, **kwargs)
 
     def __getattr__(self, name):
@@ -109,6 +119,7 @@ class GradReducer(torch.nn.Module):
             assert b.work is None, "GradReducer.zero_grad() with an all-reduce in flight: call finish() first"
             b.flat.zero_()
             b.ready.clear()
+            b.dirty = False
             off = 0
             for p in b.params:          # re-install the views if something replaced them (e.g. optimizer.zero_grad(set_to_none=True))
                 if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + off * b.flat.element_size():
@@ -118,24 +129,41 @@ class GradReducer(torch.nn.Module):
     def _launch(self, b):
         if b.work is None:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            b.dirty = False
+            b.ready.clear()
+
+    def _settle(self):
+        """wait for the exchanges in flight and turn their sums into means"""
+        for b in self._buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+                b.flat.mul_(1.0 / self.world_size)
 
     def _on_grad(self, p):
-        if self.world_size <= 1 or not self._armed:
+        if self.world_size <= 1:
             return
         b = self._bucket_of[id(p)]
+        if b.work is not None:      # forward() settles in-flight exchanges; a gradient arriving now would race with RCCL's reduction
+            raise RuntimeError("GradReducer: gradient accumulated into a bucket whose all-reduce is in flight "
+                               "(a backward ran without a forward through the wrapper since the last synchronising backward)")
+        b.dirty = True
+        if not self._armed:
+            return
         b.ready.add(id(p))
         if all((not q.requires_grad) or (id(q) in b.ready) for q in b.params):
             self._launch(b)
 
-    def finish(self, nan_to_num=True):
-        """Complete the exchange of the phase: reduce what has not been launched yet, wait, average, sanitise."""
-        if self.world_size > 1 and self._armed:
-            for b in self._buckets:         # buckets whose parameters did not all receive a gradient
-                self._launch(b)
-            for b in self._buckets:
-                b.work.wait()
-                b.work = None
-                b.flat.mul_(1.0 / self.world_size)
+    def finish(self, nan_to_num=True, reduce=True):
+        """End of a phase: exchange what no backward hook has exchanged yet (buckets whose parameters did not all receive a
+        gradient, or whose last backward ran under ``no_sync``), wait, average, sanitise.  After this every rank holds the
+        mean over ranks of everything accumulated since ``zero_grad()``.  ``reduce=False`` keeps un-exchanged gradients local."""
+        if self.world_size > 1:
+            if reduce:
+                for b in self._buckets:
+                    if b.dirty and b.work is None:
+                        self._launch(b)
+            self._settle()
         for b in self._buckets:
             b.ready.clear()
             if nan_to_num:

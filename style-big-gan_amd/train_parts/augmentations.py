@@ -149,27 +149,38 @@ class AugmentPipe(torch.nn.Module):
 
     # -- strength mirror ---------------------------------------------------------------------------------------------
     def _strength(self):
-        """Host copy of `p`.  Default: read when the buffer's version changed (one synchronising read per ADA adjustment).  With
-        `async_strength` (set by StepEngine, whose heuristic updates `p` on the device) the new value is fetched by an asynchronous
-        copy into pinned memory and adopted once that copy has completed: the sampler may use the previous strength for an
-        iteration (the heuristic moves p by ~5e-4 per adjustment), and the host never waits for the device."""
+        """Host copy of `p`, read (one synchronising read) whenever the buffer was written by someone who did not announce it --
+        construction, ``load_state_dict``, user code.  An owner that updates `p` on the device every few iterations (StepEngine's ADA
+        heuristic) announces the write instead and picks the point at which the new value takes effect, see below."""
         key = (self.p.data_ptr(), self.p._version)
         if self._p_cache[:2] != key:
-            if getattr(self, "async_strength", False) and self.p.device.type == "cuda" and self._p_cache[0] is not None:
-                pinned = torch.empty([], dtype=self.p.dtype, pin_memory=True)
-                pinned.copy_(self.p.detach(), non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.p.device))
-                self._p_pending = (pinned, ev)
-                self._p_cache = key + (self._p_cache[2],)
-            else:
-                self._p_pending = None
-                self._p_cache = key + (float(self.p),)      # synchronising read
+            self._p_pending = None
+            self._p_cache = key + (float(self.p),)
+        return self._p_cache[2]
+
+    def announce_strength_update(self):
+        """`p` has just been rewritten on the device by the caller: start an asynchronous copy of the new value into pinned memory.
+        The sampler keeps using the previous strength until ``adopt_strength()``."""
+        value = self._strength() if self._p_cache[0] is None else self._p_cache[2]
+        if self.p.device.type != "cuda":
+            self._p_cache = (self.p.data_ptr(), self.p._version, float(self.p))
+            return
+        pinned = torch.empty([], dtype=self.p.dtype, pin_memory=True)
+        pinned.copy_(self.p.detach(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.p.device))
+        self._p_pending = (pinned, ev)
+        self._p_cache = (self.p.data_ptr(), self.p._version, value)
+
+    def adopt_strength(self):
+        """Make the announced value current.  Called at a point fixed in the iteration count (one iteration after the update), so the
+        strength every sampler call sees is a function of the iteration alone -- the same on all ranks and from run to run; by then
+        the copy has completed and the event wait returns at once."""
         pend = getattr(self, "_p_pending", None)
-        if pend is not None and pend[1].query():
+        if pend is not None:
+            pend[1].synchronize()
             self._p_cache = self._p_cache[:2] + (float(pend[0]),)
             self._p_pending = None
-        return self._p_cache[2]
 
     # -- parameters --------------------------------------------------------------------------------------------------
     def sample(self, batch_size, num_channels, height, width, debug_percentile=None, p=None):

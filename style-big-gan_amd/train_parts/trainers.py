@@ -50,7 +50,7 @@ class StepEngine:
     def __init__(self, device, generator='sg2_classic', discriminator='sg2_classic', gen_kwargs=None, disc_kwargs=None,
                  loss_arch='sg2', loss='softplus', loss_arch_kwargs=None, gen_regs=(), dis_regs=(('r1', dict(r1_gamma=10.)),),
                  optim_gen=('adam', dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)), optim_disc=('adam', dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)),
-                 g_reg_interval=16, d_reg_interval=4, batch=64, batch_gpu=32, ema_kimg=10., ema_rampup=None, use_ema=True,
+                 g_reg_interval=16, d_reg_interval=4, n_dis=1, batch=64, batch_gpu=32, ema_kimg=10., ema_rampup=None, use_ema=True,
                  world_size=1, rank=0, process_group=None, seed=0,
                  augment_kwargs=None, augment_type='sg2_ada', augment_p=0.0, ada_target=None, ada_interval=4, ada_kimg=500):
         self.device = torch.device(device)
@@ -79,6 +79,8 @@ class StepEngine:
             self.dp_modules = dict(G=GradReducer(self.G, **dp), D=GradReducer(self.D, **dp))
             la = dict(G=self.dp_modules['G'])
         la.update(loss_arch_kwargs or {})
+        if self.G_ema is not None:      # G now holds rank 0's weights (the wrappers broadcast them): the average starts from those on every rank
+            misc.copy_params_and_buffers(self.G, self.G_ema, require_all=True)
 
         # discriminator augmentation + the ADA heuristic's statistics (reference trainers.py:575-584)
         self.augment_pipe, self.ada_stats = None, None
@@ -99,8 +101,7 @@ class StepEngine:
                         if v.device == acc.device:
                             acc.add_(torch.stack([torch.full([], float(v.numel()), dtype=torch.float64, device=v.device), v.sum(dtype=torch.float64)]))
                     self._ada_tap = training_stats.add_tap('Loss/signs/real', tap)
-                    self.augment_pipe._strength()               # one synchronising read of the initial strength, then lag-tolerant updates
-                    self.augment_pipe.async_strength = True
+                    self._ada_adopt_at = None                   # iteration at whose start the pipe adopts the announced strength
             la['augment_pipe'] = self.augment_pipe
         # the fused training-time synthesis layer is first order only: generator regularisers (path length) differentiate twice
         from ..torch_utils.ops import modconv
@@ -108,25 +109,46 @@ class StepEngine:
         self.loss = losses_arch[loss_arch](device=self.device, gen_regs=list(gen_regs), dis_regs=list(dis_regs),
                                            D=self.dp_modules['D'], loss=loss, **la)
 
-        # phases (reference :601-633)
+        # phases (reference :601-633).  The branch is on the interval alone: with an interval > 0 a 'reg' phase slot exists (and the
+        # optimizer's lr / betas are rescaled for it) whether or not a regulariser is configured -- the headline sg2ada.yaml has
+        # g_reg_interval = 16 and no generator regulariser, and trains G with lr * 16/17.  A slot whose program is empty draws its
+        # latents like any other phase and does nothing else (the reference's optimizer step sees no gradients there and skips).
+        # `n_dis` stretches only the un-split 'Gboth' phase (:609-610, :618).
         self.phases = []
         g_reducers = [self.dp_modules[k] for k in self.dp_modules if k.startswith('G')]
-        for name, module, reducers, (opt_name, opt_kwargs), regs, interval in [
-                ('G', self.G, g_reducers, optim_gen, gen_regs, g_reg_interval),
-                ('D', self.D, [self.dp_modules['D']], optim_disc, dis_regs, d_reg_interval)]:
-            opt_kwargs = dict(opt_kwargs)
-            if len(regs) == 0 or interval == 0 or interval is None:
-                opt = optimizers[opt_name](params=module.parameters(), **opt_kwargs)
-                self.phases.append(EasyDict(name=name + ('both' if len(regs) else 'main'), module=module, reducers=reducers, opt=opt, interval=1))
+        for name, module, reducers, (opt_name, opt_kwargs), interval, both_interval in [
+                ('G', self.G, g_reducers, optim_gen, g_reg_interval, int(n_dis)),
+                ('D', self.D, [self.dp_modules['D']], optim_disc, d_reg_interval, 1)]:
+            if interval is None or interval <= 0:
+                opt = optimizers[opt_name](params=module.parameters(), **dict(opt_kwargs))
+                slots = [(name + 'both', both_interval)]
             else:
-                opt = optimizers[opt_name](module.parameters(), **lazy_reg_opt_kwargs(opt_kwargs, interval))
-                self.phases.append(EasyDict(name=name + 'main', module=module, reducers=reducers, opt=opt, interval=1))
-                self.phases.append(EasyDict(name=name + 'reg', module=module, reducers=reducers, opt=opt, interval=interval))
+                opt = optimizers[opt_name](params=module.parameters(), **lazy_reg_opt_kwargs(dict(opt_kwargs), interval))
+                slots = [(name + 'main', 1), (name + 'reg', int(interval))]
+            for phase_name, phase_interval in slots:
+                self.phases.append(EasyDict(name=phase_name, module=module, reducers=reducers, opt=opt, interval=phase_interval,
+                                            idle=len(self.loss.program(phase_name)) == 0))
+
+    def close(self):
+        """detach from process-wide hooks (the statistics tap of the ADA heuristic) so that a later engine starts clean"""
+        tap = getattr(self, '_ada_tap', None)
+        if tap is not None:
+            training_stats.remove_tap('Loss/signs/real', tap)
+            self._ada_tap = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------------------------------------------------
     def train_iteration(self, real_img, real_c, all_gen_z=None, all_gen_c=None):
         """real_img: [batch, C, H, W] float in [-1, 1] on the device; real_c: [batch, c_dim].  One pass over the phases."""
         assert real_img.shape[0] == self.batch
+        if getattr(self, '_ada_adopt_at', None) is not None and self.batch_idx >= self._ada_adopt_at:
+            self.augment_pipe.adopt_strength()
+            self._ada_adopt_at = None
         n_phase = len(self.phases)
         if all_gen_z is None:
             all_gen_z = torch.randn([n_phase * self.batch, self.z_dim], device=self.device)
@@ -139,7 +161,7 @@ class StepEngine:
         rounds = self.batch // self.batch_gpu
 
         for phase, phase_z, phase_c in zip(self.phases, zs, cs):
-            if self.batch_idx % phase.interval != 0:
+            if phase.idle or self.batch_idx % phase.interval != 0:
                 continue
             with torch.autograd.profiler.record_function(phase.name):
                 for r in phase.reducers:
@@ -175,6 +197,9 @@ class StepEngine:
                 adjust = torch.where(acc[0] > 0, torch.sign(mean - self.ada_target) * step, torch.zeros_like(mean))
                 self.augment_pipe.p.copy_((self.augment_pipe.p + adjust.to(self.augment_pipe.p.dtype)).clamp_(min=0))
                 acc.zero_()
+                # the sampler keeps the old strength for exactly one more iteration, then switches (deterministic, identical on all ranks)
+                self.augment_pipe.announce_strength_update()
+                self._ada_adopt_at = self.batch_idx + 1
 
     # -- snapshot / resume (reference trainers.py:636-656 pickles whole modules; here plain state dicts + counters) ---------
     def state_dict(self):
@@ -200,6 +225,8 @@ class StepEngine:
             self.G_ema.load_state_dict(state.get('G_ema', state['G']), strict=strict)
         if self.augment_pipe is not None and 'augment_pipe' in state and not networks_only:
             self.augment_pipe.load_state_dict(state['augment_pipe'], strict=strict)
+            self.augment_pipe._strength()       # un-announced write: read synchronously, the resumed strength applies from the first call
+            self._ada_adopt_at = None
         if networks_only:
             return
         for ph in self.phases:
@@ -401,18 +428,13 @@ class BaseTrainer:
 
     def setup_networks(self):
         gen = self.config.gen
-        n_dis = int(gen.n_dis)
         self.engine = StepEngine(self.device(), generator=gen.generator, discriminator=gen.discriminator, gen_kwargs=self.G_kwargs,
                                  disc_kwargs=self.D_kwargs, loss_arch=gen.loss_arch, loss=gen.loss, loss_arch_kwargs=self.loss_arch_kwargs,
                                  gen_regs=self.gen_regs, dis_regs=self.dis_regs, optim_gen=self.G_opt, optim_disc=self.D_opt,
-                                 g_reg_interval=gen.g_reg_interval, d_reg_interval=gen.d_reg_interval,
+                                 g_reg_interval=gen.g_reg_interval, d_reg_interval=gen.d_reg_interval, n_dis=int(gen.n_dis),
                                  batch=self.batch_size // self.num_gpus, batch_gpu=self.batch_gpu, ema_kimg=self.config.ema.kimg,
                                  ema_rampup=self.ema_rampup, use_ema=self.config.ema.use_ema, world_size=self.num_gpus, rank=self.rank,
                                  seed=gen.seed, **self.aug)
-        if n_dis > 1:       # the generator phase runs every n_dis-th iteration (reference :609-610)
-            for phase in self.engine.phases:
-                if phase.name.startswith("G"):
-                    phase.interval = phase.interval * n_dis
 
     def setup_augmentations(self):
         self.augment_pipe = self.engine.augment_pipe        # built by StepEngine (it owns the loss object the pipe plugs into)

@@ -93,7 +93,7 @@ def test_dcgan_config_runs_on_cpu(tmp_path):
         pytest.skip("plumbing test is for the CPU container")
     trainer = starter.main(argv, max_iterations=2)
     assert trainer.engine.batch_idx == 2 and trainer.engine.cur_nimg == 32
-    assert [p.name for p in trainer.engine.phases] == ["Gmain", "Dmain"]
+    assert [p.name for p in trainer.engine.phases] == ["Gboth", "Dboth"]      # interval 0 -> un-split phases (reference trainers.py:615-618)
     assert all(torch.isfinite(p).all() for p in trainer.engine.G.parameters())
     dry = starter.main(argv + ["exp.dry_run=true"])
     assert not hasattr(dry, "engine")

@@ -106,7 +106,7 @@ def test_dcgan_plumbing_runs_on_cpu():
                               loss_arch="base", loss="bcew", gen_regs=[], dis_regs=[],
                               optim_gen=("adam", dict(lr=2e-4, betas=[0.5, 0.9])), optim_disc=("adam", dict(lr=2e-4, betas=[0.5, 0.9])),
                               g_reg_interval=0, d_reg_interval=0, batch=16, batch_gpu=16, use_ema=False)
-    assert [p.name for p in eng.phases] == ["Gmain", "Dmain"]
+    assert [p.name for p in eng.phases] == ["Gboth", "Dboth"]
     before = [p.detach().clone() for p in eng.G.parameters()]
     eng.train_iteration(torch.rand(16, 3, 32, 32) * 2 - 1, None)
     assert any(not torch.equal(a, b) for a, b in zip(before, eng.G.parameters()))
@@ -117,3 +117,33 @@ def test_lazy_regularisation_phases():
     from style_big_gan_amd.train_parts import trainers
     kw = trainers.lazy_reg_opt_kwargs(dict(lr=0.0025, betas=[0, 0.99]), 4)
     assert abs(kw["lr"] - 0.0025 * 0.8) < 1e-12 and abs(kw["betas"][1] - 0.99 ** 0.8) < 1e-12
+
+
+def test_phase_construction_follows_the_interval_alone():
+    """reference trainers.py:615-627 branches on reg_interval only.  sg2ada.yaml: g_reg_interval 16 and NO generator regulariser still
+    gives Gmain + an (idle) Greg slot and scales G's Adam to lr * 16/17, beta2 ** (16/17); D: interval 4 with R1.  n_dis stretches only
+    an un-split 'Gboth' phase (:609-610, :618); with interval 0 the phases are 'Gboth' / 'Dboth'."""
+    from style_big_gan_amd.train_parts import trainers
+    tiny = dict(generator="cnn32_dcgan", discriminator="cnn32_dcgan", gen_kwargs=dict(z_dim=8, c_dim=0, img_resolution=32), disc_kwargs=dict(),
+                loss_arch="base", loss="softplus", batch=4, batch_gpu=4, use_ema=False,
+                optim_gen=("adam", dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)), optim_disc=("adam", dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)))
+    eng = trainers.StepEngine("cpu", gen_regs=[], dis_regs=[("r1", dict(r1_gamma=0.01))], g_reg_interval=16, d_reg_interval=4, n_dis=3, **tiny)
+    assert [(p.name, p.interval, p.idle) for p in eng.phases] == [("Gmain", 1, False), ("Greg", 16, True), ("Dmain", 1, False), ("Dreg", 4, False)]
+    g_opt, d_opt = eng.phases[0].opt.param_groups[0], eng.phases[2].opt.param_groups[0]
+    assert eng.phases[0].opt is eng.phases[1].opt and eng.phases[2].opt is eng.phases[3].opt
+    assert abs(g_opt["lr"] - 0.0025 * 16 / 17) < 1e-15 and abs(g_opt["lr"] - 0.002353) < 1e-6
+    assert tuple(g_opt["betas"]) == (0.0, 0.99 ** (16 / 17)) and abs(g_opt["betas"][1] - 0.99058) < 1e-5
+    assert abs(d_opt["lr"] - 0.0025 * 4 / 5) < 1e-15 and tuple(d_opt["betas"]) == (0.0, 0.99 ** (4 / 5))
+    # the idle slot neither steps the optimizer nor touches its moments, but four phases' worth of latents are drawn per iteration
+    drawn = []
+    randn = torch.randn
+    torch.randn = lambda *a, **k: (drawn.append(a[0]) if a and isinstance(a[0], (list, tuple)) and len(a[0]) == 2 else None, randn(*a, **k))[1]
+    try:
+        eng.train_iteration(torch.rand(4, 3, 32, 32) * 2 - 1, None)
+    finally:
+        torch.randn = randn
+    assert [4 * 4, 8] in [list(d) for d in drawn]
+    assert all(int(st["step"]) == 1 for st in eng.phases[0].opt.state.values())      # Gmain stepped once, the idle Greg not at all
+    eng = trainers.StepEngine("cpu", gen_regs=[], dis_regs=[], g_reg_interval=0, d_reg_interval=0, n_dis=3, **tiny)
+    assert [(p.name, p.interval) for p in eng.phases] == [("Gboth", 3), ("Dboth", 1)]
+    assert eng.phases[0].opt.param_groups[0]["lr"] == 0.0025

@@ -59,16 +59,48 @@ def _worker(rank, world, init_file, results):
         y.square().mean().backward()
         assert all(b.work is None for b in red._buckets)
         local = [p.grad.clone() for p in net.parameters()]
-        red._armed = False
-        red.finish()
+        red.finish(reduce=False)
         for p, l in zip(net.parameters(), local):
             assert torch.equal(p.grad, l)
+
+        # a phase whose last backward ran under no_sync is still exchanged when it ends: finish() leaves the mean on every rank
+        red.zero_grad()
+        with misc.ddp_sync(red, sync=False):
+            y = red(xs[0])
+        y.square().mean().backward()
+        red.finish()
+        for p, l in zip(net.parameters(), local):
+            g = l.clone()
+            dist.all_reduce(g)
+            assert torch.allclose(p.grad, g / world, atol=1e-6)
+
+        # SEVERAL synchronising backwards between zero_grad() and finish() -- what the path-length and gradient-penalty regularisers
+        # do (calc_reg gets sync=True on every accumulation round, reference losses_base.py:94,109): the result must be the mean over
+        # ranks of the sum over rounds, and no backward may accumulate into a bucket that is still being reduced
+        for n_rounds in (2, 3):
+            red.zero_grad()
+            xr = [torch.randn(5, 6) for _ in range(n_rounds)]
+            for x in xr:
+                with misc.ddp_sync(red, sync=True):
+                    y = red(x)
+                y.square().mean().backward()
+            red.finish()
+            for q in ref.parameters():
+                q.grad = None
+            for x in xr:
+                ref(x).square().mean().backward()
+            for p, q in zip(net.parameters(), ref.parameters()):
+                g = q.grad.clone()
+                dist.all_reduce(g)
+                assert torch.allclose(p.grad, g / world, atol=1e-6), "repeated synchronising backwards: wrong gradient"
+            both = [torch.zeros_like(red._buckets[0].flat) for _ in range(world)]
+            dist.all_gather(both, red._buckets[0].flat)
+            assert torch.equal(both[0], both[1]), "ranks hold different gradients after finish()"
 
         # nan_to_num on the flat buckets
         red.zero_grad()
         red._buckets[0].flat[0] = float("nan"); red._buckets[0].flat[1] = float("inf")
-        red._armed = False
-        red.finish()
+        red.finish(reduce=False)
         assert float(red._buckets[0].flat[0]) == 0.0 and float(red._buckets[0].flat[1]) == 1e5
 
         # optimizer step on the reduced gradients keeps ranks identical
@@ -92,21 +124,58 @@ def _worker(rank, world, init_file, results):
         dist.destroy_process_group()
 
 
-def test_grad_reducer_world2_gloo():
-    world = 2
+def _engine_worker(rank, world, init_file, results):
+    """StepEngine over two ranks: a 'Dboth' phase with the gradient penalty (its own synchronising D pass in EVERY accumulation round,
+    after the adversarial pass -- the schedule that used to corrupt the flat buckets), two rounds per iteration, Adam + EMA; every
+    rank must end with rank 0's G, D and G_ema (G_ema starts from the broadcast weights, not from the rank's own initialisation)."""
+    sys.path.insert(0, ROOT)
+    import style_big_gan_amd  # noqa: F401
+    from style_big_gan_amd.torch_utils import misc
+    from style_big_gan_amd.train_parts import trainers
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        eng = trainers.StepEngine("cpu", generator="cnn32_dcgan", discriminator="cnn32_dcgan", gen_kwargs=dict(z_dim=8, c_dim=0, img_resolution=32),
+                                  disc_kwargs=dict(), loss_arch="base", loss="wasserstein", gen_regs=[], dis_regs=[("grad_pen", dict(alpha=10.))],
+                                  optim_gen=("adam", dict(lr=1e-3, betas=[0.5, 0.9])), optim_disc=("adam", dict(lr=1e-3, betas=[0.5, 0.9])),
+                                  g_reg_interval=0, d_reg_interval=0, batch=4, batch_gpu=2, ema_kimg=0.01, world_size=world, rank=rank, seed=3)
+        assert [p.name for p in eng.phases] == ["Gboth", "Dboth"]
+        misc.check_ddp_consistency(eng.G); misc.check_ddp_consistency(eng.D); misc.check_ddp_consistency(eng.G_ema)
+        d0 = [p.detach().clone() for p in eng.D.parameters()]
+        torch.manual_seed(50 + rank)                    # different reals and latents on each rank
+        for _ in range(2):
+            eng.train_iteration(torch.rand(4, 3, 32, 32) * 2 - 1, None)
+        assert any(not torch.equal(a, b) for a, b in zip(d0, eng.D.parameters()))
+        local_bn = r".*\.(running_mean|running_var|num_batches_tracked)"      # batch-norm statistics are per rank (broadcast_buffers=False, reference :592)
+        for m in (eng.G, eng.D, eng.G_ema):
+            misc.check_ddp_consistency(m, ignore_regex=local_bn)
+        assert eng.cur_nimg == 2 * 4 * world
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world(target, world=2):
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "rdzv")
         mgr = mp.Manager()
         results = mgr.dict()
         ctx = mp.get_context("spawn")
-        procs = [ctx.Process(target=_worker, args=(r, world, init_file, results)) for r in range(world)]
+        procs = [ctx.Process(target=target, args=(r, world, init_file, results)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
             p.join(timeout=180)
         for p in procs:
             assert p.exitcode == 0, f"worker exit code {p.exitcode}"
-        assert dict(results) == {0: "ok", 1: "ok"}
+        assert dict(results) == {r: "ok" for r in range(world)}
+
+
+def test_grad_reducer_world2_gloo():
+    _run_world(_worker)
+
+
+def test_step_engine_world2_repeated_sync_and_ema():
+    _run_world(_engine_worker)
 
 
 def test_grad_reducer_single_process():
