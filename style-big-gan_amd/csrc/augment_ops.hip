@@ -282,7 +282,7 @@ extern "C" int sbg_grid_sample2d(const sbg_grid_sample_params* p, sbg_stream_t s
     const int64_t total = (int64_t)a.N * a.OH * a.OW;
     const double bytes = 4.0 * ((double)a.N * a.C * a.IH * a.IW + (double)total * a.C + (a.grid ? 2.0 * total : 0.0));
     SbgProfScope prof(stream, SBG_K_GRID_SAMPLE, 0.0, bytes, {a.N, a.C, a.IH, a.IW, a.OH, a.OW, 0});
-    hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(sbg_stream_grid(total, 256)), dim3(256), 0, stream, a);
+    SBG_LAUNCH(grid_sample_fwd_kernel, dim3(sbg_stream_grid(total, 256)), dim3(256), 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -306,12 +306,12 @@ extern "C" int sbg_grid_sample2d_bwd(const sbg_grid_sample_params* p, sbg_stream
     if (sbg_grid_sample2d_bwd_overwrites(p)) {
         SbgProfScope prof(stream, SBG_K_GRID_SAMPLE, 0.0, bytes, {a.N, a.C, a.IH, a.IW, a.OH, a.OW, 2});
         const int64_t in_total = (int64_t)a.N * a.IH * a.IW;
-        hipLaunchKernelGGL(grid_sample_bwd_gather_kernel, dim3((unsigned)((in_total + 255) / 256)), dim3(256), 0, stream, a);
+        SBG_LAUNCH(grid_sample_bwd_gather_kernel, dim3((unsigned)((in_total + 255) / 256)), dim3(256), 0, stream, a);
         SBG_HIP_LAUNCH_CHECK();
         return 0;
     }
     SbgProfScope prof(stream, SBG_K_GRID_SAMPLE, 0.0, bytes, {a.N, a.C, a.IH, a.IW, a.OH, a.OW, 1});
-    hipLaunchKernelGGL(grid_sample_bwd_kernel, dim3(sbg_stream_grid(total, 256)), dim3(256), 0, stream, a);
+    SBG_LAUNCH(grid_sample_bwd_kernel, dim3(sbg_stream_grid(total, 256)), dim3(256), 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -332,7 +332,7 @@ extern "C" int sbg_filter1d_batch(const float* x, const float* taps, float* y, i
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t total = (int64_t)M * a.OH * a.OW;
     SbgProfScope prof(stream, SBG_K_FILTER1D, 0.0, 4.0 * ((double)M * H * W + (double)total), {M, H, W, T, axis, pad, 0});
-    hipLaunchKernelGGL(filter1d_batch_kernel, dim3(sbg_stream_grid(total, 256)), dim3(256), 0, stream, a);
+    SBG_LAUNCH(filter1d_batch_kernel, dim3(sbg_stream_grid(total, 256)), dim3(256), 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -345,7 +345,7 @@ extern "C" int sbg_color_transform(const float* x, const float* M, float* y, int
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t quads = (HW + 3) / 4;
     SbgProfScope prof(stream, SBG_K_COLOR, 0.0, 4.0 * 6.0 * (double)N * HW, {N, 3, (int)HW, 0, 0, 0, 0});
-    hipLaunchKernelGGL(color_transform_kernel, dim3(sbg_stream_grid((int64_t)N * quads, 256)), dim3(256), 0, stream, x, M, y, N, HW, quads);
+    SBG_LAUNCH(color_transform_kernel, dim3(sbg_stream_grid((int64_t)N * quads, 256)), dim3(256), 0, stream, x, M, y, N, HW, quads);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -144,10 +144,10 @@ static int launch_bias_act(const BiasActArgs& p, bool vec, hipStream_t stream)
     SbgProfScope prof(stream, SBG_K_BIAS_ACT, 0.0, (double)p.sizeX * es * streams, {(int)p.sizeX, p.grad, A, es});
     if (vec) {
         unsigned grid = sbg_stream_grid((p.sizeX >> 3) + 1, 256);
-        hipLaunchKernelGGL((bias_act_vec8<T, A>), dim3(grid), dim3(256), 0, stream, p);
+        SBG_LAUNCH((bias_act_vec8<T, A>), dim3(grid), dim3(256), 0, stream, p);
     } else {
         unsigned grid = sbg_stream_grid(p.sizeX, 256);
-        hipLaunchKernelGGL((bias_act_scalar<T, A>), dim3(grid), dim3(256), 0, stream, p);
+        SBG_LAUNCH((bias_act_scalar<T, A>), dim3(grid), dim3(256), 0, stream, p);
     }
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;

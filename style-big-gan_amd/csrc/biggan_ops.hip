@@ -156,12 +156,12 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* theta, 
 }
 
 template <int MT>
-static void launch_att(const float* theta, const float* phi, const float* g, float* out, int N, int Q, int M, int D, int DV, hipStream_t s)
+static int launch_att(const float* theta, const float* phi, const float* g, float* out, int N, int Q, int M, int D, int DV, hipStream_t s)
 {
     const int lds = 4 * 16 * (ATT_MAX_M + 4) * (int)sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attention_fwd_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL((attention_fwd_kernel<MT>), dim3((Q + 63) / 64, N), dim3(256), lds, s, theta, phi, g, out, Q, M, D, DV);
+    if (!SBG_RAISE_LDS_ONCE(attention_fwd_kernel<MT>, lds)) return sbg_fail(SBG_ERR_LAUNCH, "attention_fwd: cannot raise the dynamic LDS limit to %d bytes", lds);
+    SBG_LAUNCH((attention_fwd_kernel<MT>), dim3((Q + 63) / 64, N), dim3(256), lds, s, theta, phi, g, out, Q, M, D, DV);
+    return SBG_OK;
 }
 
 } // namespace
@@ -185,10 +185,10 @@ extern "C" int sbg_sn_power_iteration(const float* W, const float* u, float* v, 
     float* vn2 = v_raw + cols;
     float* t = vn2 + kb;
     SbgProfScope prof(s, SBG_K_SN_POWER, 4.0 * rows * (double)cols, 8.0 * rows * (double)cols, {rows, cols});
-    hipLaunchKernelGGL(sn_colsum_kernel, dim3(kb, nrb), dim3(256), 0, s, W, u, partial, rows, cols);
-    hipLaunchKernelGGL(sn_vfinish_kernel, dim3(kb), dim3(256), 0, s, partial, v_raw, vn2, cols, nrb);
-    hipLaunchKernelGGL(sn_rowsum_kernel, dim3(rows), dim3(256), 0, s, W, v_raw, vn2, kb, v, t, rows, cols, eps);
-    hipLaunchKernelGGL(sn_ufinish_kernel, dim3(1), dim3(256), 0, s, t, u_new, sigma, rows, eps);
+    SBG_LAUNCH(sn_colsum_kernel, dim3(kb, nrb), dim3(256), 0, s, W, u, partial, rows, cols);
+    SBG_LAUNCH(sn_vfinish_kernel, dim3(kb), dim3(256), 0, s, partial, v_raw, vn2, cols, nrb);
+    SBG_LAUNCH(sn_rowsum_kernel, dim3(rows), dim3(256), 0, s, W, v_raw, vn2, kb, v, t, rows, cols, eps);
+    SBG_LAUNCH(sn_ufinish_kernel, dim3(1), dim3(256), 0, s, t, u_new, sigma, rows, eps);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -206,14 +206,16 @@ extern "C" int sbg_attention_fwd(const float* theta, const float* phi, const flo
     if (N == 0) return SBG_OK;
     hipStream_t s = (hipStream_t)stream;
     SbgProfScope prof(s, SBG_K_ATTENTION, 2.0 * N * (double)Q * M * (D + DV), 4.0 * N * ((double)Q * D + (double)M * (D + DV) + (double)Q * DV), {N, Q, M, D, DV});
+    int rc = SBG_OK;
     switch (M / 16) {
-        case 1:  launch_att<1>(theta, phi, g, out, N, Q, M, D, DV, s); break;
-        case 2:  launch_att<2>(theta, phi, g, out, N, Q, M, D, DV, s); break;
-        case 4:  launch_att<4>(theta, phi, g, out, N, Q, M, D, DV, s); break;
-        case 8:  launch_att<8>(theta, phi, g, out, N, Q, M, D, DV, s); break;
-        case 16: launch_att<16>(theta, phi, g, out, N, Q, M, D, DV, s); break;
+        case 1:  rc = launch_att<1>(theta, phi, g, out, N, Q, M, D, DV, s); break;
+        case 2:  rc = launch_att<2>(theta, phi, g, out, N, Q, M, D, DV, s); break;
+        case 4:  rc = launch_att<4>(theta, phi, g, out, N, Q, M, D, DV, s); break;
+        case 8:  rc = launch_att<8>(theta, phi, g, out, N, Q, M, D, DV, s); break;
+        case 16: rc = launch_att<16>(theta, phi, g, out, N, Q, M, D, DV, s); break;
         default: return sbg_fail(SBG_ERR_UNSUPPORTED, "attention_fwd: M / 16 must be 1, 2, 4, 8 or 16 (got M = %d)", M);
     }
+    if (rc != SBG_OK) return rc;
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }

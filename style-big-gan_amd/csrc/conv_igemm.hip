@@ -229,7 +229,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream)
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
                       {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, BC * 1000 + BP});
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    SBG_LAUNCH(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -366,17 +366,13 @@ static int launch_conv_dma(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipS
     if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
     constexpr int lds = NSTAGE * (BC * 64 + BP * 64);
     auto kern = conv_igemm_dma_kernel<MF, BC, BP, WGC, WGP, NSTAGE, MINW>;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024 && !SBG_RAISE_LDS_ONCE(kern, lds))
+        return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
     const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
                       {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, BC * 1000 + BP});
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WGC * WGP * 64), lds, stream, a, x_bytes, w_bytes);
+    SBG_LAUNCH(kern, dim3((unsigned)nblk), dim3(WGC * WGP * 64), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -388,7 +384,7 @@ static int dispatch_conv(ConvArgs& a, int64_t x_bytes, int64_t w_bytes, bool all
     const bool dma = allow_dma && x_bytes < (int64_t)SBG_OOB_OFFSET && w_bytes < (int64_t)SBG_OOB_OFFSET;
     // tile choice: few output channels -> pixel-heavy tile; otherwise 128 x 128.
     if (dma) {
-        const char* v = getenv("SBG_CONV_TILE");      // experiment switch (tile / pipeline-depth variants)
+        const char* v = sbg_env("SBG_CONV_TILE");      // experiment switch (tile / pipeline-depth variants)
         const int variant = v ? atoi(v) : 0;
         if (a.Cout <= 64) return launch_conv_dma<MF, 64, 256, 1, 4, 4, 1>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);
         if (variant == 1) return launch_conv_dma<MF, 128, 256, 2, 4, 3, 4>(a, (unsigned)x_bytes, (unsigned)w_bytes, stream);   // 8 waves, 2 WG/CU
@@ -404,7 +400,7 @@ static int dispatch_conv(ConvArgs& a, int64_t x_bytes, int64_t w_bytes, bool all
 
 static int phase_min_tiles()        // experiment switch: smallest tile count for which a transposed convolution runs as ONE multi-phase launch
 {
-    static const char* e = getenv("SBG_PHASE_MIN_TILES");
+    static const char* e = sbg_env("SBG_PHASE_MIN_TILES");
     return e ? atoi(e) : 16;            // 256 -> 16: the 4x4 .. 32x32 up-sampling layers as one launch instead of four latency-bound ones (-1.4 ms per step)
 }
 
@@ -446,7 +442,7 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     for (int t = 0; t < q->ntaps; t++) { SBG_CHECK(q->tap_slab[t] >= 0, "conv2d_igemm: negative weight slab"); if (q->tap_slab[t] > maxslab) maxslab = q->tap_slab[t]; }
     const int64_t x_bytes = 2 * ((int64_t)(q->N - 1) * q->xs_n + (int64_t)(q->IH - 1) * q->xs_h + (int64_t)(q->IW - 1) * q->xs_w + q->Cin);
     const int64_t w_bytes = 2 * ((int64_t)maxslab * q->ws_slab + (int64_t)(q->Cout - 1) * q->ws_co + q->Cin);
-    const bool allow_dma = getenv("SBG_CONV_NO_DMA") == nullptr && q->xs_n >= 0 && q->xs_h >= 0 && q->xs_w >= 0 && q->ws_slab >= 0 && q->ws_co >= 0;
+    const bool allow_dma = sbg_env("SBG_CONV_NO_DMA") == nullptr && q->xs_n >= 0 && q->xs_h >= 0 && q->xs_w >= 0 && q->ws_slab >= 0 && q->ws_co >= 0;
     if (q->nphase > 1) {
         // phases: one persistent launch when the shape fits that kernel, otherwise one launch per phase through this same entry point
         SBG_CHECK(q->nphase <= 4, "conv2d_igemm: at most 4 phases");
@@ -461,7 +457,7 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
         }
         SBG_CHECK(t0 <= q->ntaps, "conv2d_igemm: phases use %d taps, %d given", t0, q->ntaps);
         const int64_t tiles = ((ptot / q->nphase + 255) / 256) * q->nphase * ((q->Cout + 127) / 128);
-        if (allow_dma && q->Cout > 64 && tiles >= phase_min_tiles() && x_bytes < (int64_t)0x80000000u && w_bytes < (int64_t)0x80000000u && getenv("SBG_CONV_NO_PHASES") == nullptr) {
+        if (allow_dma && q->Cout > 64 && tiles >= phase_min_tiles() && x_bytes < (int64_t)0x80000000u && w_bytes < (int64_t)0x80000000u && sbg_env("SBG_CONV_NO_PHASES") == nullptr) {
             a.nphase = q->nphase;
             const int rc = sbg_conv_k64_dispatch(a, q->xdtype == SBG_BF16, x_bytes, w_bytes, nullptr, 1, s);
             if (rc >= 0) return rc;

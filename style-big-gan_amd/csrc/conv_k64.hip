@@ -42,12 +42,8 @@ template <int N, class F>
 static __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }   // compile-time unrolled loop
 
 template <int N> static __device__ __forceinline__ void wait_vmcnt_const() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-// Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
-// e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
-// Fast path (Cout % 8 == 0, 16-B aligned output rows and per-channel vectors): no per-element guards, branch-free
-// activation (leaky ReLU with alpha 0 / 1 covers ReLU / linear; clamp = med3 with an infinite bound when disabled), one
-// 16-B store per 8 channels.  Everything else takes the guarded element-wise path.
-// Straight-line fast path: the output dtype and "no epilogue math" are template parameters, every 8-channel group of the
+
+// Straight-line fast path of the epilogue (layout of the accumulators: see conv_epilogue8 below): the output dtype and "no epilogue math" are template parameters, every 8-channel group of the
 // wave is in range and 16-B aligned (checked by the caller), so the loops below carry no per-element guards and no dtype
 // branches: leaky ReLU with alpha 0 / 1 covers ReLU / linear, clamp = med3 with an infinite bound when disabled.
 template <int TC, int TP, int YDT, bool PLAIN, bool NUNI, class PixFn>
@@ -113,71 +109,6 @@ static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, flo
     }
 }
 
-// Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
-// e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
-// Fast path (Cout % 8 == 0, 16-B aligned output rows and per-channel vectors): no per-element guards, branch-free
-// activation (leaky ReLU with alpha 0 / 1 covers ReLU / linear; clamp = med3 with an infinite bound when disabled), one
-// 16-B store per 8 channels.  Everything else takes the guarded element-wise path.
-// Straight-line fast path: the output dtype and "no epilogue math" are template parameters, every 8-channel group of the
-// wave is in range and 16-B aligned (checked by the caller), so the loops below carry no per-element guards and no dtype
-// branches: leaky ReLU with alpha 0 / 1 covers ReLU / linear, clamp = med3 with an infinite bound when disabled.
-template <int TC, int TP, int YDT, bool PLAIN, class PixFn>
-static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix)
-{
-    constexpr int TH2 = TC / 2;
-    const float alpha = (p.act == SBG_ACT_LRELU) ? p.alpha : (p.act == SBG_ACT_RELU ? 0.f : 1.f);
-    const float cl = p.clamp >= 0.f ? p.clamp : __builtin_inff();
-    const float gain = p.gain;
-    float4_t bias_lo[TH2], bias_hi[TH2];
-    if (!PLAIN) {
-#pragma unroll
-        for (int h = 0; h < TH2; h++) {
-            bias_lo[h] = bias_hi[h] = float4_t{0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
-                const float* b = p.bias + cbase + 32 * h + 8 * fg;
-                bias_lo[h] = *reinterpret_cast<const float4_t*>(b);
-                bias_hi[h] = *reinterpret_cast<const float4_t*>(b + 4);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < TP; j++) {
-        int n, oy, ox;
-        if (!pix(j, n, oy, ox)) continue;
-        const int64_t yoff = (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
-        float nz = 0.f;
-        if (!PLAIN && p.noise) nz = p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox];
-        const float* sc = p.oscale + (int64_t)n * p.Cout + cbase + 8 * fg;
-#pragma unroll
-        for (int h = 0; h < TH2; h++) {
-            float4_t lo = acc[2 * h][j], hi = acc[2 * h + 1][j];
-            if (!PLAIN) {
-                if (p.oscale) {
-                    lo *= *reinterpret_cast<const float4_t*>(sc + 32 * h);
-                    hi *= *reinterpret_cast<const float4_t*>(sc + 32 * h + 4);
-                }
-                lo += nz + bias_lo[h];
-                hi += nz + bias_hi[h];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float u = lo[e]; u = (u > 0.f) ? u : u * alpha; lo[e] = __builtin_amdgcn_fmed3f(u * gain, -cl, cl);
-                    float w = hi[e]; w = (w > 0.f) ? w : w * alpha; hi[e] = __builtin_amdgcn_fmed3f(w * gain, -cl, cl);
-                }
-            }
-            if (YDT == SBG_F32) {
-                float* dst = (float*)p.y + yoff + 32 * h;
-                if (p.accumulate) { lo += *reinterpret_cast<float4_t*>(dst); hi += *reinterpret_cast<float4_t*>(dst + 4); }
-                *reinterpret_cast<float4_t*>(dst) = lo;
-                *reinterpret_cast<float4_t*>(dst + 4) = hi;
-            } else {
-                short8_t o;
-#pragma unroll
-                for (int e = 0; e < 4; e++) { o[e] = (short)f32_to_bf16_bits(lo[e]); o[4 + e] = (short)f32_to_bf16_bits(hi[e]); }
-                *reinterpret_cast<short8_t*>((unsigned short*)p.y + yoff + 32 * h) = o;
-            }
-        }
-    }
-}
 
 // Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
 // e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
@@ -860,19 +791,15 @@ static int launch_gather_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hip
     if (nblk > ncu) nblk = ncu;     // persistent: one workgroup per CU, each walks tiles b, b + grid, ...
     a.ph_rot_div = (int)(nblk / ((int64_t)a.ctiles * a.nphase)); if (a.ph_rot_div < 1) a.ph_rot_div = 1;
     auto kern = conv_gather_ld_kernel<MF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
-        attr_set = true;
-    }
+    if (!SBG_RAISE_LDS_ONCE(kern, lds))
+        return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
     const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
     double macs = 0.0, outpix = 0.0;
     for (int i = 0; i < a.nphase; i++) { macs += (double)a.ph_P[i] * a.ph_ntaps[i]; outpix += a.ph_P[i]; }
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * macs * a.Cout * (double)a.Cin,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * outpix * (double)a.Cout * (a.accumulate ? 2 : 1),
                       {(int)outpix, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 4128256 + (a.nphase > 1 ? 1000000 * a.nphase : 0)});
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(768), lds, stream, a, x_bytes, w_bytes);
+    SBG_LAUNCH(kern, dim3((unsigned)nblk), dim3(768), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -895,17 +822,13 @@ static int launch_halo_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipSt
     }
     if (nblk > ncu) nblk = ncu;     // persistent: one workgroup per CU (the LDS footprint admits no more), each walks tiles b, b + grid, ...
     auto kern = conv_halo_ld_kernel<MF, TH, TW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
-        attr_set = true;
-    }
+    if (!SBG_RAISE_LDS_ONCE(kern, lds))
+        return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
     const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
                       {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 3128256});
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(768), lds, stream, a, x_bytes, w_bytes);
+    SBG_LAUNCH(kern, dim3((unsigned)nblk), dim3(768), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -920,17 +843,13 @@ static int launch_k64(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream
     const int64_t nblk = (int64_t)a.ptiles * a.ctiles;
     if (nblk > INT32_MAX) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
     auto kern = conv_k64_kernel<MF, BC, BP, WGC, WGP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
-        attr_set = true;
-    }
+    if (!SBG_RAISE_LDS_ONCE(kern, lds))
+        return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
     const double ys = a.ydtype == SBG_F32 ? 4.0 : 2.0;
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * a.P * a.Cout * (double)a.Cin * a.ntaps,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * a.P * (double)a.Cout * (a.accumulate ? 2 : 1),
                       {a.P, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 1000000 + BC * 1000 + BP});
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)(a.ksplit > 1 ? a.ksplit : 1)), dim3(512), lds, stream, a, x_bytes, w_bytes);
+    SBG_LAUNCH(kern, dim3((unsigned)nblk, (unsigned)(a.ksplit > 1 ? a.ksplit : 1)), dim3(512), lds, stream, a, x_bytes, w_bytes);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -1001,7 +920,7 @@ static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStr
     if (tiles256 < 256) return launch_k64<MF, 128, 128, 2, 4>(a, xb, wb, stream);
     // short reductions (transposed-conv phases: 1-4 taps) gain from the persistent pipeline; measured: +4..10 % at <= 8 K-steps per tile,
     // -5 % at 18+ (the 8-wave kernel's in-wave DMA issue overlaps better there)
-    static const char* egl = getenv("SBG_K64_GATHER_LD");        // experiment switch: 0 never, 1 always
+    static const char* egl = sbg_env("SBG_K64_GATHER_LD");        // experiment switch: 0 never, 1 always
     const int ksteps = a.ntaps * ((a.Cin + 63) >> 6);
     if (egl ? atoi(egl) != 0 : (ksteps >= 2 && ksteps <= 8)) return launch_gather_ld<MF>(a, xb, wb, stream);      // 1 step: store-bound, the plain kernel wins
     return launch_k64<MF, 128, 256, 2, 4>(a, xb, wb, stream);
@@ -1030,11 +949,11 @@ int sbg_conv_k64_dispatch(ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_byt
     if (x_bytes >= (int64_t)SBG_OOB_OFFSET || w_bytes >= (int64_t)SBG_OOB_OFFSET) return -1;
     if (a.xs_n < 0 || a.xs_h < 0 || a.xs_w < 0 || a.ws_slab < 0 || a.ws_co < 0) return -1;
     // experiment switch: SBG_CONV_K64 = 0 off / 1 gather only / 2 (default) gather + halo
-    const char* e1 = getenv("SBG_CONV_K64");
+    const char* e1 = sbg_env("SBG_CONV_K64");
     const int level = e1 ? atoi(e1) : 2;
     if (level <= 0) return -1;
 #ifdef SBG_K64_DEBUG
-    { const char* e3 = getenv("SBG_K64_ABL"); a.debug = e3 ? atoi(e3) : 0; }
+    { const char* e3 = sbg_env("SBG_K64_ABL"); a.debug = e3 ? atoi(e3) : 0; }
 #endif
     const unsigned xb = (unsigned)x_bytes, wb = (unsigned)w_bytes;
     const int64_t y_numel = (int64_t)a.P * a.Cout;
@@ -1052,10 +971,10 @@ int sbg_conv_k64_dispatch(ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_byt
         if (rc != SBG_OK) return rc;
         if (simple) {
             unsigned grid = (unsigned)((y_numel + 15) / 16); if (grid > 4096) grid = 4096;
-            hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)workspace, (float*)y, y_numel, k, acc);
+            SBG_LAUNCH(conv_ksplit_reduce_kernel, dim3(grid), dim3(256), 0, stream, (const float*)workspace, (float*)y, y_numel, k, acc);
         } else {
             unsigned grid = (unsigned)((y_numel / 8 + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
-            hipLaunchKernelGGL(conv_ksplit_reduce_epi_kernel, dim3(grid), dim3(256), 0, stream, (const float*)workspace, a, y_numel, k);
+            SBG_LAUNCH(conv_ksplit_reduce_epi_kernel, dim3(grid), dim3(256), 0, stream, (const float*)workspace, a, y_numel, k);
         }
         SBG_HIP_LAUNCH_CHECK();
         return SBG_OK;

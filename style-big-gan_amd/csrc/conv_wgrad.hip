@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
 static void plan_split_target(WgradArgs& a, int bca, int bcb, int target);
 static void plan_split(WgradArgs& a, int bca, int bcb)
 {
-    static const char* e = getenv("SBG_WGRAD_TARGET");      // experiment switch: workgroups aimed for (tiles x pixel splits)
+    static const char* e = sbg_env("SBG_WGRAD_TARGET");      // experiment switch: workgroups aimed for (tiles x pixel splits)
     plan_split_target(a, bca, bcb, e ? atoi(e) : 1024);
 }
 static void plan_split_target(WgradArgs& a, int bca, int bcb, int target)
@@ -415,14 +415,14 @@ static bool use_big_tile(int ntaps) { return ntaps == 1; }
 
 static int rows_bca(const WgradArgs& a)      // a-tile width of the rows kernel: 128 halves the staged bytes per MFMA
 {
-    static const char* e = getenv("SBG_WGRAD_BCA");
+    static const char* e = sbg_env("SBG_WGRAD_BCA");
     if (e) return atoi(e) == 64 ? 64 : 128;
     return (a.stride == 2 && a.Ca >= 128) ? 128 : 64;     // measured: +46 % at stride 2 (65-column b patch), -7 % at stride 1
 }
 
 static bool rows_kernel_ok(const sbg_wgrad_params* q, const WgradArgs& a)
 {
-    if (getenv("SBG_WGRAD_NO_DMA")) return false;
+    if (sbg_env("SBG_WGRAD_NO_DMA")) return false;
     if ((q->stride != 1 && q->stride != 2) || (q->PW % 32) != 0 || q->ntaps != 9) return false;
     for (int t = 0; t < 9; t++)          // the kernel hard-codes a row-major 3x3 tap window starting at (dy[0], dx[0])
         if (q->tap_dy[t] != q->tap_dy[0] + t / 3 || q->tap_dx[t] != q->tap_dx[0] + t % 3) return false;
@@ -460,16 +460,12 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t stream)
 {
     constexpr int lds = 32 * (BCA * 2 + 32) + NT * 32 * (BCB * 2 + 32);
     auto kern = conv_wgrad_kernel<MF, BCA, BCB, NT>;
-    static bool attr_set = false;     // idempotent; racing threads set the same value
-    if (lds > 64 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return sbg_fail(SBG_ERR_LAUNCH, "conv2d_wgrad: cannot raise the dynamic LDS limit to %d bytes", lds);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024 && !SBG_RAISE_LDS_ONCE(kern, lds))
+        return sbg_fail(SBG_ERR_LAUNCH, "conv2d_wgrad: cannot raise the dynamic LDS limit to %d bytes", lds);
     SbgProfScope prof(stream, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                       2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
                       {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, BCA * 1000 + BCB});
-    hipLaunchKernelGGL(kern, dim3(wgrad_grid(a)), dim3(256), lds, stream, a);
+    SBG_LAUNCH(kern, dim3(wgrad_grid(a)), dim3(256), lds, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -505,11 +501,11 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
         // stage = (a pieces + 3 x patch pieces, rounded up to 8) KiB
         auto stage_kib = [](int S, int BCA) { const int ppr = (S * 31 + 3 + 7) / 8; return ((BCA / 16 + 3 * ppr + 7) / 8) * 8; };
         // stride 2 with the 128-channel a tile: 40 KB stages -- two of them (80 KB) admit two workgroups per CU, three do not
-        static const char* ens = getenv("SBG_WGRAD_NSTAGE");
+        static const char* ens = sbg_env("SBG_WGRAD_NSTAGE");
         const int nst = (s_ == 2 && bca == 128 && !(ens && atoi(ens) == 3)) ? 2 : 3;
         const int lds = nst * stage_kib(s_, bca) * 1024;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::once_flag rows_lds_once;
+        std::call_once(rows_lds_once, [&] {
             const int big = 3 * stage_kib(2, 128) * 1024;
             (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -521,13 +517,12 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
             (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            attr_set = true;
-        }
+        });
         SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                           2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
                           {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, bca * 1000 + 64});
         const dim3 grid(wgrad_grid(a));
-#define SBG_ROWS_LAUNCH(MFT, SS, BB, NS) hipLaunchKernelGGL((conv_wgrad_rows_kernel<MFT, SS, BB, NS>), grid, dim3(512), lds, s, a, ab, bb)
+#define SBG_ROWS_LAUNCH(MFT, SS, BB, NS) SBG_LAUNCH((conv_wgrad_rows_kernel<MFT, SS, BB, NS>), grid, dim3(512), lds, s, a, ab, bb)
         if (s_ == 1 && bca == 64)       { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 64, 3);  else SBG_ROWS_LAUNCH(f16_mfma, 1, 64, 3); }
         else if (s_ == 1)               { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 128, 3); else SBG_ROWS_LAUNCH(f16_mfma, 1, 128, 3); }
         else if (bca == 64)             { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 64, 3);  else SBG_ROWS_LAUNCH(f16_mfma, 2, 64, 3); }
@@ -552,11 +547,11 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
     if (a.nsplit > 1) {
         SbgProfScope prof(s, SBG_K_WGRAD_REDUCE, 0.0, 4.0 * out_n * (a.nsplit + 1), {(int)out_n, a.nsplit});
         if (out_n >= (1 << 18) || a.nsplit < 16)      // plenty of elements: one lane each, coalesced across lanes
-            hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(sbg_stream_grid(out_n, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
+            SBG_LAUNCH(wgrad_reduce_kernel<1>, dim3(sbg_stream_grid(out_n, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
         else if (out_n >= (1 << 14))
-            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(sbg_stream_grid(out_n * 4, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
+            SBG_LAUNCH(wgrad_reduce_kernel<4>, dim3(sbg_stream_grid(out_n * 4, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
         else
-            hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(sbg_stream_grid(out_n * 64, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
+            SBG_LAUNCH(wgrad_reduce_kernel<64>, dim3(sbg_stream_grid(out_n * 64, 256)), dim3(256), 0, s, a.ws, a.out, out_n, a.nsplit, a.accumulate);
         SBG_HIP_LAUNCH_CHECK();
     }
     return SBG_OK;

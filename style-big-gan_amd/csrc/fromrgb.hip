@@ -220,8 +220,8 @@ extern "C" int sbg_fromrgb_fwd(const float* img, const float* w, const float* bi
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_FROMRGB, 2.0 * N * Co * (double)Ci * HW, (double)N * HW * (2.0 * Co + 4.0 * Ci), {N, Ci, Co, (int)HW, 0, 0, 0});
     dim3 grid((unsigned)(N * a.blocks_per_n)), block(256);
-    if (dtype == SBG_BF16) hipLaunchKernelGGL(fromrgb_fwd_kernel<bf16_s>, grid, block, 0, stream, a);
-    else                   hipLaunchKernelGGL(fromrgb_fwd_kernel<f16_s>, grid, block, 0, stream, a);
+    if (dtype == SBG_BF16) SBG_LAUNCH(fromrgb_fwd_kernel<bf16_s>, grid, block, 0, stream, a);
+    else                   SBG_LAUNCH(fromrgb_fwd_kernel<f16_s>, grid, block, 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -240,8 +240,8 @@ extern "C" int sbg_fromrgb_bwd(const float* img, const float* w, const void* dy,
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_FROMRGB, 4.0 * N * Co * (double)Ci * HW, (double)N * HW * (4.0 * Co + 8.0 * Ci), {N, Ci, Co, (int)HW, 1, 0, 0});
     dim3 grid((unsigned)(N * a.blocks_per_n)), block(256);
-    if (dtype == SBG_BF16) hipLaunchKernelGGL(fromrgb_bwd_kernel<bf16_s>, grid, block, 0, stream, a);
-    else                   hipLaunchKernelGGL(fromrgb_bwd_kernel<f16_s>, grid, block, 0, stream, a);
+    if (dtype == SBG_BF16) SBG_LAUNCH(fromrgb_bwd_kernel<bf16_s>, grid, block, 0, stream, a);
+    else                   SBG_LAUNCH(fromrgb_bwd_kernel<f16_s>, grid, block, 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }

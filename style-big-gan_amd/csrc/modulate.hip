@@ -247,10 +247,10 @@ static int run_scale(const ScaleArgs& a0, int layout, bool vec, hipStream_t s)
     SbgProfScope prof(s, SBG_K_SCALE_NC, 0.0, 2.0 * es * a.N * (double)a.C * a.HW, {a.N, a.C, (int)a.HW, layout});
     if (vec) {
         a.total = (int64_t)a.N * a.HW * (a.C >> 3);
-        hipLaunchKernelGGL((scale_nc_cminor8<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, s, a);
+        SBG_LAUNCH((scale_nc_cminor8<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, s, a);
     } else {
         a.total = (int64_t)a.N * a.HW * a.C;
-        hipLaunchKernelGGL((scale_nc_scalar<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, s, a, layout);
+        SBG_LAUNCH((scale_nc_scalar<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, s, a, layout);
     }
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
@@ -261,8 +261,8 @@ static int run_dot(const DotArgs& a, int layout, bool fast, hipStream_t s)
 {
     const double es = sizeof(T) == 4 ? 4 : 2;
     SbgProfScope prof(s, SBG_K_DOT_HW, 0.0, (a.v ? 2.0 : 1.0) * es * a.N * (double)a.C * a.HW, {a.N, a.C, (int)a.HW, layout});
-    if (fast) hipLaunchKernelGGL((dot_hw_cminor8<T>), dim3(a.N, a.nsplit), dim3(256), 0, s, a);
-    else      hipLaunchKernelGGL((dot_hw_generic<T>), dim3((unsigned)((int64_t)a.N * a.C)), dim3(256), 0, s, a, layout);
+    if (fast) SBG_LAUNCH((dot_hw_cminor8<T>), dim3(a.N, a.nsplit), dim3(256), 0, s, a);
+    else      SBG_LAUNCH((dot_hw_generic<T>), dim3((unsigned)((int64_t)a.N * a.C)), dim3(256), 0, s, a, layout);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }
@@ -358,9 +358,9 @@ extern "C" int sbg_modconv_bwd(const void* dy, const void* y, const float* dcoef
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype == SBG_F32 ? 4 : 2;
     SbgProfScope prof(s, SBG_K_DOT_HW, 0.0, 3.0 * es * N * (double)C * HW, {N, C, (int)HW, 2});
-    if (dtype == SBG_F32)      hipLaunchKernelGGL((modconv_bwd_kernel<float>), dim3(N, p.nsplit), dim3(256), 0, s, p);
-    else if (dtype == SBG_F16) hipLaunchKernelGGL((modconv_bwd_kernel<f16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
-    else                       hipLaunchKernelGGL((modconv_bwd_kernel<bf16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    if (dtype == SBG_F32)      SBG_LAUNCH((modconv_bwd_kernel<float>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    else if (dtype == SBG_F16) SBG_LAUNCH((modconv_bwd_kernel<f16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    else                       SBG_LAUNCH((modconv_bwd_kernel<bf16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }

@@ -5,6 +5,7 @@
 #include <string>
 #include <cstdio>
 #include <cstdarg>
+#include <mutex>
 #include "../../include/sbg_hip.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -26,6 +27,26 @@ static inline int sbg_fail(int code, const char* fmt, ...)
 #define SBG_CHECK(cond, ...) do { if (!(cond)) return sbg_fail(SBG_ERR_INVALID, __VA_ARGS__); } while (0)
 #define SBG_HIP_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) return sbg_fail(SBG_ERR_LAUNCH, "%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+// Launch geometry is validated on the host BEFORE anything is enqueued: a dispatch packet with a zero grid dimension, more than 1024
+// work-items per workgroup or more LDS than a CU owns must never reach the queue (the runtime's own checks run after the fact, and
+// a tool that intercepts the queue -- rocprofv3 counter collection -- sees the packet as it was built).
+bool sbg_launch_geometry_ok(dim3 grid, dim3 block, size_t lds_bytes, const char* kernel, const char* file, int line);
+
+#define SBG_LAUNCH_OR(on_error, kern, grid, block, lds, stream, ...) do { \
+    const dim3 sbg_g_ = (grid), sbg_b_ = (block); \
+    if (!sbg_launch_geometry_ok(sbg_g_, sbg_b_, (size_t)(lds), #kern, __FILE__, __LINE__)) { on_error; } \
+    hipLaunchKernelGGL(kern, sbg_g_, sbg_b_, (lds), (stream), __VA_ARGS__); } while (0)
+#define SBG_LAUNCH(kern, grid, block, lds, stream, ...) SBG_LAUNCH_OR(return SBG_ERR_INVALID, kern, grid, block, lds, stream, __VA_ARGS__)
+
+// One-time, thread-safe raise of a kernel's dynamic-LDS limit (forward runs on the caller's thread, backward on autograd's workers).
+// Evaluates to true when the limit is in place.
+#define SBG_RAISE_LDS_ONCE(kern, bytes) ([&]() -> bool { static std::once_flag once_; static bool ok_ = false; \
+    std::call_once(once_, [&] { ok_ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) == hipSuccess; }); \
+    return ok_; }())
+
+// Experiment switches (SBG_* environment variables) are read once per process, never on the launch path.
+const char* sbg_env(const char* name);      // cached getenv: the first call per name scans `environ`, later calls are a table lookup
 
 // ------------------------------------------------------------------------------------------------
 // 16-bit float storage <-> fp32 math.

@@ -7,14 +7,43 @@ std::string& sbg_err_slot()
     return slot;
 }
 
-extern "C" int sbg_version(void) { return 1; }
+extern "C" int sbg_version(void) { return 2; }
+
+bool sbg_launch_geometry_ok(dim3 grid, dim3 block, size_t lds_bytes, const char* kernel, const char* file, int line)
+{
+    const uint64_t threads = (uint64_t)block.x * block.y * block.z;
+    const bool ok = grid.x > 0 && grid.y > 0 && grid.z > 0 && grid.y <= 65535u && grid.z <= 65535u && block.x > 0 && block.y > 0 && block.z > 0
+                 && threads <= 1024 && lds_bytes <= 160u * 1024u
+                 && (uint64_t)grid.x * block.x <= 0xffffffffull;      // the dispatch packet's grid_size fields are 32-bit work-item counts
+    if (!ok)
+        (void)sbg_fail(SBG_ERR_INVALID, "%s:%d: refusing to launch %s with grid (%u, %u, %u), block (%u, %u, %u), %zu bytes of LDS",
+                       file, line, kernel, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds_bytes);
+    return ok;
+}
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+const char* sbg_env(const char* name)
+{
+    static std::mutex mu;
+    static std::map<std::string, std::pair<bool, std::string>> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find(name);
+    if (it == seen.end()) {
+        const char* v = getenv(name);
+        it = seen.emplace(name, std::make_pair(v != nullptr, std::string(v ? v : ""))).first;
+    }
+    return it->second.first ? it->second.second.c_str() : nullptr;
+}
 
 extern "C" const char* sbg_last_error(void) { return sbg_err_slot().c_str(); }
 
 // ------------------------------------------------------------------------------------------------
 // Launch timing log.
 #include <vector>
-#include <mutex>
 #include <atomic>
 
 namespace {

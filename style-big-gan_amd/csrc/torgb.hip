@@ -224,8 +224,8 @@ extern "C" int sbg_torgb_fwd(const void* x, const float* wmod, const float* bias
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_TORGB, 2.0 * N * O * (double)C * HW, (double)N * HW * (2.0 * C + 4.0 * O), {N, C, O, (int)HW, 0, 0, 0});
     dim3 grid((unsigned)(N * a.blocks_per_n)), block(256);
-    if (dtype == SBG_BF16) hipLaunchKernelGGL(torgb_fwd_kernel<bf16_s>, grid, block, 0, stream, a);
-    else                   hipLaunchKernelGGL(torgb_fwd_kernel<f16_s>, grid, block, 0, stream, a);
+    if (dtype == SBG_BF16) SBG_LAUNCH(torgb_fwd_kernel<bf16_s>, grid, block, 0, stream, a);
+    else                   SBG_LAUNCH(torgb_fwd_kernel<f16_s>, grid, block, 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -242,8 +242,8 @@ extern "C" int sbg_torgb_bwd(const void* x, const float* wmod, const float* dy, 
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_TORGB, 4.0 * N * O * (double)C * HW, (double)N * HW * (4.0 * C + 8.0 * O), {N, C, O, (int)HW, 1, 0, 0});
     dim3 grid((unsigned)(N * a.blocks_per_n)), block(256);
-    if (dtype == SBG_BF16) hipLaunchKernelGGL(torgb_bwd_kernel<bf16_s>, grid, block, 0, stream, a);
-    else                   hipLaunchKernelGGL(torgb_bwd_kernel<f16_s>, grid, block, 0, stream, a);
+    if (dtype == SBG_BF16) SBG_LAUNCH(torgb_bwd_kernel<bf16_s>, grid, block, 0, stream, a);
+    else                   SBG_LAUNCH(torgb_bwd_kernel<f16_s>, grid, block, 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }

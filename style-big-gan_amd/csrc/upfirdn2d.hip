@@ -417,19 +417,15 @@ static bool launch_fir_mfma_rpw(const UpfirdnArgs& a, hipStream_t stream)
     const int64_t nblk = (int64_t)a.N * tiles_y * tiles_x * cblocks;
     if (nblk > INT32_MAX || nblk <= 0) return false;
     auto kern = upfirdn2d_fir_mfma_kernel<T, RPW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, tiles_y, cblocks);
+    if (!SBG_RAISE_LDS_ONCE(kern, lds)) return false;
+    SBG_LAUNCH(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, tiles_y, cblocks);
     return true;
 }
 
 template <class T>
 static bool launch_fir_mfma(const UpfirdnArgs& a, hipStream_t stream)
 {
-    static const char* e = getenv("SBG_FIR_RPW");        // experiment switch: 1 = 4 x 32 tiles (3 workgroups per CU)
+    static const char* e = sbg_env("SBG_FIR_RPW");        // experiment switch: 1 = 4 x 32 tiles (3 workgroups per CU)
     if (e && atoi(e) == 1) return launch_fir_mfma_rpw<T, 1>(a, stream);
     if (e && atoi(e) == 4) return launch_fir_mfma_rpw<T, 4>(a, stream);
     return launch_fir_mfma_rpw<T, 2>(a, stream);
@@ -447,7 +443,7 @@ static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, bool exact16, hipStr
                       es * ((double)a.N * a.C * a.inH * a.inW + (double)a.N * a.C * a.outH * a.outW),
                       {a.N, a.C, a.inH, a.inW, a.outH, a.outW, a.upx * 16 + a.downx});
     if (vec8 && exact16 && sizeof(T) == 2 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw == 4 && a.fh == 4 && (a.C % 64) == 0
-        && a.outW >= 16 && a.outH >= 8 && getenv("SBG_FIR_NO_MFMA") == nullptr && try_fir_mfma<T>(a, stream)) {
+        && a.outW >= 16 && a.outH >= 8 && sbg_env("SBG_FIR_NO_MFMA") == nullptr && try_fir_mfma<T>(a, stream)) {
         // matrix-core FIR
     } else if (a.tail) {
         return sbg_fail(SBG_ERR_UNSUPPORTED, "upfirdn2d: fused tail requested but the matrix-core FIR path does not take this launch");
@@ -455,15 +451,15 @@ static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, bool exact16, hipStr
         const int xblocks = (a.outW + FIR_TX - 1) / FIR_TX, yblocks = (a.outH + FIR_TY - 1) / FIR_TY;
         a.total = (int64_t)a.N * yblocks * xblocks * (a.C >> 3);
         if (a.fw == 4 && a.fh == 4)
-            hipLaunchKernelGGL((upfirdn2d_fir_fixed_kernel<T, 4, 4>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a, xblocks, yblocks);
+            SBG_LAUNCH((upfirdn2d_fir_fixed_kernel<T, 4, 4>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a, xblocks, yblocks);
         else
-            hipLaunchKernelGGL((upfirdn2d_fir_kernel<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a, xblocks, yblocks);
+            SBG_LAUNCH((upfirdn2d_fir_kernel<T>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a, xblocks, yblocks);
     } else if (vec8) {
         a.total = (int64_t)a.N * a.outH * a.outW * (a.C >> 3);
-        hipLaunchKernelGGL((upfirdn2d_kernel<T, 8>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a);
+        SBG_LAUNCH((upfirdn2d_kernel<T, 8>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a);
     } else {
         a.total = (int64_t)a.N * a.outH * a.outW * a.C;
-        hipLaunchKernelGGL((upfirdn2d_kernel<T, 1>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a);
+        SBG_LAUNCH((upfirdn2d_kernel<T, 1>), dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a);
     }
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
@@ -477,7 +473,7 @@ extern "C" int sbg_upfirdn2d_tail_supported(const sbg_upfirdn2d_params* q)
     const int C = q->inSize[2];
     return (q->dtype == SBG_BF16 || q->dtype == SBG_F16) && q->filter_exact16 && q->upx == 1 && q->upy == 1 && q->downx == 1 && q->downy == 1
            && q->filterSize[0] == 4 && q->filterSize[1] == 4 && (C % 64) == 0 && q->outSize[0] >= 16 && q->outSize[1] >= 8
-           && q->inStride[2] == 1 && q->outStride[2] == 1 && getenv("SBG_FIR_NO_MFMA") == nullptr;
+           && q->inStride[2] == 1 && q->outStride[2] == 1 && sbg_env("SBG_FIR_NO_MFMA") == nullptr;
 }
 
 extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)

@@ -126,10 +126,10 @@ extern "C" int sbg_upfirdn2d_separable(const float* x, const float* f, float* y,
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_UPFIRDN2D, 0.0, 4.0 * ((double)M * IH * IW + (double)M * OH * OW), {M, 1, IH, IW, OH, OW, 100 + up * 10 + down});
     dim3 grid((unsigned)blocks), block(256);
-    if (up == 1 && down == 1)      hipLaunchKernelGGL((upfirdn2d_sep_kernel<1, 1>), grid, block, 0, stream, a);
-    else if (up == 2 && down == 1) hipLaunchKernelGGL((upfirdn2d_sep_kernel<2, 1>), grid, block, 0, stream, a);
-    else if (up == 1 && down == 2) hipLaunchKernelGGL((upfirdn2d_sep_kernel<1, 2>), grid, block, 0, stream, a);
-    else                           hipLaunchKernelGGL((upfirdn2d_sep_kernel<2, 2>), grid, block, 0, stream, a);
+    if (up == 1 && down == 1)      SBG_LAUNCH((upfirdn2d_sep_kernel<1, 1>), grid, block, 0, stream, a);
+    else if (up == 2 && down == 1) SBG_LAUNCH((upfirdn2d_sep_kernel<2, 1>), grid, block, 0, stream, a);
+    else if (up == 1 && down == 2) SBG_LAUNCH((upfirdn2d_sep_kernel<1, 2>), grid, block, 0, stream, a);
+    else                           SBG_LAUNCH((upfirdn2d_sep_kernel<2, 2>), grid, block, 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -82,9 +82,9 @@ extern "C" int sbg_pack_weight(const float* w, void* out, int out_dtype, int A, 
     const int64_t total = (int64_t)A * Bp;
     SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 0.0, (double)A * B * KH * KW * (4.0 + sbg_dtype_size(out_dtype)), {A, B, KH * KW, 0, 0, 0, 0});
     dim3 grid(sbg_stream_grid(total, 256)), block(256);
-    if (out_dtype == SBG_BF16)      hipLaunchKernelGGL(pack_weight_kernel<bf16_s>, grid, block, 0, stream, a);
-    else if (out_dtype == SBG_F16)  hipLaunchKernelGGL(pack_weight_kernel<f16_s>, grid, block, 0, stream, a);
-    else if (out_dtype == SBG_F32)  hipLaunchKernelGGL(pack_weight_kernel<float>, grid, block, 0, stream, a);
+    if (out_dtype == SBG_BF16)      SBG_LAUNCH(pack_weight_kernel<bf16_s>, grid, block, 0, stream, a);
+    else if (out_dtype == SBG_F16)  SBG_LAUNCH(pack_weight_kernel<f16_s>, grid, block, 0, stream, a);
+    else if (out_dtype == SBG_F32)  SBG_LAUNCH(pack_weight_kernel<float>, grid, block, 0, stream, a);
     else return sbg_fail(SBG_ERR_INVALID, "pack_weight: bad dtype %d", out_dtype);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
@@ -101,7 +101,7 @@ extern "C" int sbg_unpack_wgrad(const float* dwp, int64_t dwp_tap_stride, int64_
     a.pT = dwp_tap_stride; a.pA = dwp_row_stride; a.sA = sA; a.sB = sB; a.sKH = sKH; a.sKW = sKW; a.gain = gain;
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 0.0, (double)A * B * KH * KW * 8.0, {A, B, KH * KW, 1, 0, 0, 0});
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(sbg_stream_grid((int64_t)A * B, 256)), dim3(256), 0, stream, a);
+    SBG_LAUNCH(unpack_wgrad_kernel, dim3(sbg_stream_grid((int64_t)A * B, 256)), dim3(256), 0, stream, a);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -182,7 +182,7 @@ extern "C" int sbg_demod_coefs(const float* styles, const float* w2, float* dcoe
     SBG_CHECK(styles && w2 && dcoefs && N >= 1 && O >= 1 && I >= 1, "demod_coefs: bad arguments");
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 2.0 * N * O * (double)I, 4.0 * ((double)N * I + (double)O * I + (double)N * O), {N, O, I, 2, 0, 0, 0});
-    hipLaunchKernelGGL(demod_coefs_kernel, dim3((unsigned)(((int64_t)N * O + 3) / 4)), dim3(256), 0, stream, styles, w2, dcoefs, N, O, I, eps);
+    SBG_LAUNCH(demod_coefs_kernel, dim3((unsigned)(((int64_t)N * O + 3) / 4)), dim3(256), 0, stream, styles, w2, dcoefs, N, O, I, eps);
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -196,11 +196,11 @@ extern "C" int sbg_demod_coefs_bwd(const float* g, const float* dcoefs, const fl
     SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 4.0 * N * O * (double)I, 4.0 * (2.0 * N * I + 2.0 * O * I + 2.0 * N * O), {N, O, I, 3, 0, 0, 0});
     if (dstyles) {
         const int chunks = (I + 63) / 64;
-        hipLaunchKernelGGL(demod_bwd_styles_kernel, dim3((unsigned)(N * chunks)), dim3(256), (O + 256) * sizeof(float), stream, g, dcoefs, styles, w2, dstyles, N, O, I);
+        SBG_LAUNCH(demod_bwd_styles_kernel, dim3((unsigned)(N * chunks)), dim3(256), (O + 256) * sizeof(float), stream, g, dcoefs, styles, w2, dstyles, N, O, I);
         SBG_HIP_LAUNCH_CHECK();
     }
     if (dw2) {
-        hipLaunchKernelGGL(demod_bwd_w2_kernel, dim3((unsigned)(((int64_t)O * I + 255) / 256)), dim3(256), 0, stream, g, dcoefs, styles, dw2, N, O, I);
+        SBG_LAUNCH(demod_bwd_w2_kernel, dim3((unsigned)(((int64_t)O * I + 255) / 256)), dim3(256), 0, stream, g, dcoefs, styles, dw2, N, O, I);
         SBG_HIP_LAUNCH_CHECK();
     }
     return 0;

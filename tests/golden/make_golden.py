@@ -351,6 +351,198 @@ def gen_biggan():
         arrays[f"gradD/{name}"] = npy(g_ if g_ is not None else torch.zeros_like(p_))
     save("biggan_networks", arrays, cfg)
 
+# ---------------------------------------------------------------------------------------------------------------- hybrid + host step
+
+class _ConstNoise(torch.nn.Module):
+    """harness wrapper: the loss code calls ``G_synthesis(ws)``, whose default noise mode draws fresh noise from the device's
+    generator on every call; the fixtures pin the synthesis network with its registered constant noise instead"""
+
+    def __init__(self, synthesis):
+        super().__init__()
+        self.synthesis = synthesis
+
+    def forward(self, ws):
+        return self.synthesis(ws, noise_mode='const')
+
+
+def _build_sg2(RG, RD, g_kw, d_kw, seed):
+    import copy
+    torch.manual_seed(seed)
+    g_kw, d_kw = copy.deepcopy(g_kw), copy.deepcopy(d_kw)
+    ed = dnnlib.EasyDict
+    G = RG.generators['sg2_classic'](**{k: (ed(v) if isinstance(v, dict) else v) for k, v in g_kw.items()})
+    D = RD.discriminators['sg2_classic'](**{k: (ed(v) if isinstance(v, dict) else v) for k, v in d_kw.items()})
+    with torch.no_grad():
+        for m in list(G.modules()) + list(D.modules()):
+            if type(m).__name__ == 'Attention':
+                m.gamma.fill_(0.6)
+        for name, p in list(G.named_parameters()) + list(D.named_parameters()):
+            if name.endswith("noise_strength"):
+                p.fill_(0.3)
+            if name.endswith(".bias") and "affine" not in name:
+                p.copy_(torch.randn_like(p) * 0.1)
+    return G.train(), D.train()
+
+
+def gen_sg2attent():
+    """configs/sg2attent.yaml's architecture at 16x16: the reference's ``train_parts`` StyleGAN2 blocks with the non-local attention
+    hook at the end of the block (generators.py:443-445, discriminators.py:297-299): G attention at every resolution, D attention
+    at 16 (applied to its 8x8 output) and 8.  Forward + one Gmain / Dmain / R1 gradient set, as in gen_networks."""
+    RG, RD = _import_train_parts()
+    res, cb, cm = 16, 256, 32
+    g_kw = dict(z_dim=16, c_dim=0, w_dim=24, img_resolution=res, img_channels=3, attentions=[16, 8, 4], mapping_kwargs=dict(num_layers=2),
+                synthesis_kwargs=dict(channel_base=cb, channel_max=cm, block_kwargs=dict(architecture='skip', layer_kwargs=dict())))
+    d_kw = dict(c_dim=0, img_resolution=res, img_channels=3, attentions=[16, 8], architecture='orig', channel_base=cb, channel_max=cm,
+                block_kwargs=dict(), mapping_kwargs=dict(), epilogue_kwargs=dict(mbstd_group_size=2))
+    G, D = _build_sg2(RG, RD, g_kw, d_kw, seed=400)
+    n = 4
+    z, z2, real = torch.randn(n, 16), torch.randn(n, 16), torch.randn(n, 3, res, res)
+    c = torch.zeros(n, 0)
+    arrays = dict(z=npy(z), z2=npy(z2), real=npy(real))
+    arrays.update(state_arrays(G, "G")); arrays.update(state_arrays(D, "D"))
+    for p in D.parameters(): p.requires_grad_(False)
+    ws = G.mapping(z, c, skip_w_avg_update=True)
+    img = G.synthesis(ws, noise_mode='const')
+    logits = D(img, c)
+    loss_g = torch.nn.functional.softplus(-logits).mean()
+    loss_g.backward()
+    arrays.update(ws=npy(ws), img=npy(img), logits=npy(logits), loss_g=npy(loss_g))
+    for name, p in G.named_parameters():
+        arrays[f"gradG/{name}"] = npy(p.grad if p.grad is not None else torch.zeros_like(p))
+    arrays.update({f"G_after/{k}": npy(v) for k, v in G.state_dict().items() if k.endswith(('u0', 'sv0'))})      # power iteration ran once per SN layer
+    for p in G.parameters(): p.requires_grad_(False)
+    for p in D.parameters(): p.requires_grad_(True)
+    with torch.no_grad():
+        fake = G.synthesis(G.mapping(z2, c, skip_w_avg_update=True), noise_mode='const')
+    real_in = real.clone().requires_grad_(True)
+    real_logits = D(real_in, c)
+    loss_d = torch.nn.functional.softplus(-real_logits).mean() + torch.nn.functional.softplus(D(fake, c)).mean()
+    loss_d.backward(retain_graph=True)
+    arrays.update(loss_d=npy(loss_d), real_logits=npy(real_logits))
+    for name, p in D.named_parameters():
+        arrays[f"gradD/{name}"] = npy(p.grad if p.grad is not None else torch.zeros_like(p)); p.grad = None
+    r1 = torch.autograd.grad(real_logits.sum(), real_in, create_graph=True)[0]
+    pen = (r1.square().sum([1, 2, 3]) * (0.5 / 2)).mean()
+    pen.backward()
+    arrays["r1_penalty"] = npy(pen)
+    for name, p in D.named_parameters():
+        arrays[f"gradR1/{name}"] = npy(p.grad if p.grad is not None else torch.zeros_like(p))
+    save("sg2attent", arrays, dict(g_kwargs=g_kw, d_kwargs=d_kw, r1_gamma=0.5))
+
+
+def _run_reference_schedule(cfg, tag):
+    """Drive the REFERENCE's loss / regulariser objects (train_parts/losses_base.py SG2Loss, regularizations.py R1reg / PPLreg) through the
+    iteration body of its training loop.  ``train_parts/trainers.py`` itself does not import here (wandb), so its loop is re-enacted
+    from the description in SURVEY.md section 8(c): phase table of :601-633 (main / reg slots per network when the interval is positive,
+    optimizer rescaled by interval / (interval + 1)), and per iteration (:711-765) latents for every slot, then for each slot that is
+    due: clear gradients -> requires_grad on -> accumulation rounds of accumulate_gradients(gain = interval, sync on the last) ->
+    requires_grad off -> nan_to_num of the gradients -> optimizer step; then the generator average and the image counter.
+    Everything random is captured: latents and reals are stored per iteration, the path-length direction is recorded as it is drawn."""
+    import copy
+    RG, RD = _import_train_parts()
+    import train_parts.losses_base as R_lb
+    from stylegan2ada.torch_utils import training_stats as R_stats
+    from stylegan2ada.torch_utils import misc as R_misc
+    G, D = _build_sg2(RG, RD, cfg['g_kwargs'], cfg['d_kwargs'], seed=cfg['seed'])
+    G.requires_grad_(False); D.requires_grad_(False)
+    G_ema = copy.deepcopy(G).eval()
+    arrays = {}
+    arrays.update(state_arrays(G, "G0")); arrays.update(state_arrays(D, "D0"))
+    loss = R_lb.losses_arch['sg2'](device=torch.device('cpu'), loss=cfg['loss'], gen_regs=cfg['gen_regs'], dis_regs=cfg['dis_regs'], D=D,
+                                   G_mapping=G.mapping, G_synthesis=_ConstNoise(G.synthesis), style_mixing_prob=0)
+    slots = []
+    for name, module, interval in [('G', G, cfg['g_reg_interval']), ('D', D, cfg['d_reg_interval'])]:
+        kw = dict(cfg['opt'])
+        if interval <= 0:
+            opt = torch.optim.Adam(module.parameters(), **kw)
+            slots.append(dict(name=name + 'both', module=module, opt=opt, interval=1))
+        else:
+            ratio = interval / (interval + 1)
+            kw['lr'] = kw['lr'] * ratio
+            kw['betas'] = [b ** ratio for b in kw['betas']]
+            opt = torch.optim.Adam(module.parameters(), **kw)
+            slots.append(dict(name=name + 'main', module=module, opt=opt, interval=1))
+            slots.append(dict(name=name + 'reg', module=module, opt=opt, interval=interval))
+    B, b = cfg['batch'], cfg['batch_gpu']
+    collector = R_stats.Collector(regex='.*')
+    collector.update()          # forget whatever earlier generators of this process reported
+    pl_noise_log = []
+    real_randn_like = torch.randn_like
+
+    def recording_randn_like(t, *a, **k):       # the only randn_like on this path is the path-length direction (regularizations.py:26)
+        out = real_randn_like(t, *a, **k)
+        pl_noise_log.append(out.clone())
+        return out
+
+    torch.manual_seed(cfg['seed'] + 1)
+    cur_nimg = 0
+    for it in range(cfg['iterations']):
+        reals = torch.randn(B, 3, cfg['g_kwargs']['img_resolution'], cfg['g_kwargs']['img_resolution']).clamp(-1, 1)
+        all_z = torch.randn(len(slots) * B, G.z_dim)
+        arrays[f"it{it}/real"], arrays[f"it{it}/all_gen_z"] = npy(reals), npy(all_z)
+        c = torch.zeros(B, 0)
+        for slot, slot_z in zip(slots, all_z.split(B)):
+            if it % slot['interval'] != 0:
+                continue
+            slot['opt'].zero_grad(set_to_none=True)
+            slot['module'].requires_grad_(True)
+            rounds = B // b
+            torch.randn_like = recording_randn_like
+            try:
+                for r in range(rounds):
+                    sl = slice(r * b, (r + 1) * b)
+                    loss.accumulate_gradients(phase=slot['name'], real_img=reals[sl], real_c=c[sl], gen_z=slot_z[sl], gen_c=c[sl],
+                                              sync=(r == rounds - 1), gain=slot['interval'])
+            finally:
+                torch.randn_like = real_randn_like
+            slot['module'].requires_grad_(False)
+            for p in slot['module'].parameters():
+                if p.grad is not None:
+                    R_misc.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
+            slot['opt'].step()
+        ema_nimg = cfg['ema_kimg'] * 1000
+        if cfg['ema_rampup'] is not None:
+            ema_nimg = min(ema_nimg, cur_nimg * cfg['ema_rampup'])
+        beta = 0.5 ** (B / max(ema_nimg, 1e-8))
+        with torch.no_grad():
+            for pe, p in zip(G_ema.parameters(), G.parameters()):
+                pe.copy_(p.lerp(pe, beta))
+            for be, b_ in zip(G_ema.buffers(), G.buffers()):
+                be.copy_(b_)
+        cur_nimg += B
+        arrays.update(state_arrays(G, f"it{it}/G")); arrays.update(state_arrays(D, f"it{it}/D")); arrays.update(state_arrays(G_ema, f"it{it}/G_ema"))
+    for i, t in enumerate(pl_noise_log):
+        arrays[f"pl_noise/{i}"] = npy(t)
+    if loss.gen_regs is not None:
+        arrays["pl_mean"] = npy(loss.gen_regs[0].pl_mean)
+    collector.update()
+    stats = {name: dict(mean=float(collector.mean(name)), num=int(collector.num(name))) for name in collector.names() if name.startswith('Loss/')}
+    save(f"host_step_{tag}", arrays, dict(cfg=cfg, slots=[dict(name=s_['name'], interval=s_['interval']) for s_ in slots], stats=stats,
+                                           n_pl_noise=len(pl_noise_log)))
+
+
+def gen_host_step():
+    res, cb, cm = 16, 256, 32
+    base_g = dict(z_dim=16, c_dim=0, w_dim=24, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=2),
+                  synthesis_kwargs=dict(channel_base=cb, channel_max=cm, block_kwargs=dict(architecture='skip', layer_kwargs=dict())))
+    base_d = dict(c_dim=0, img_resolution=res, img_channels=3, architecture='orig', channel_base=cb, channel_max=cm, block_kwargs=dict(),
+                  mapping_kwargs=dict(), epilogue_kwargs=dict(mbstd_group_size=2))
+    # Adam's eps is raised from the configs' 1e-8 to 1e-4: with beta1 = 0 the first update is lr * g / (|g| + eps), which at eps = 1e-8
+    # amplifies the last bit of any gradient near zero to a full +-lr step; the schedule, gains and rescaling under test do not depend on it
+    opt = dict(lr=0.0025, betas=[0, 0.99], eps=1e-4)
+    # (1) sg2ada.yaml's schedule: lazy R1 on D, NO generator regulariser but a positive g_reg_interval (idle Greg slot, rescaled G optimizer);
+    #     two accumulation rounds per phase
+    _run_reference_schedule(dict(g_kwargs=base_g, d_kwargs=base_d, seed=500, loss='softplus', gen_regs=[], dis_regs=[['r1', dict(r1_gamma=0.5)]],
+                                 g_reg_interval=4, d_reg_interval=2, opt=opt, batch=4, batch_gpu=2, iterations=3, ema_kimg=0.02, ema_rampup=0.5), "r1")
+    # (2) ffhq_sg2.yaml's schedule: path-length regulariser on G (weight 2, batch shrink 2) + R1 on a resnet D, mapping depth 3
+    import copy
+    g2, d2 = copy.deepcopy(base_g), copy.deepcopy(base_d)
+    g2['mapping_kwargs']['num_layers'] = 3
+    d2['architecture'] = 'resnet'
+    _run_reference_schedule(dict(g_kwargs=g2, d_kwargs=d2, seed=510, loss='softplus',
+                                 gen_regs=[['ppl', dict(pl_batch_shrink=2, pl_decay=0.01, pl_weight=2.)]], dis_regs=[['r1', dict(r1_gamma=1.0)]],
+                                 g_reg_interval=2, d_reg_interval=2, opt=opt, batch=4, batch_gpu=4, iterations=3, ema_kimg=0.02, ema_rampup=None), "ppl")
+
 
 # ---------------------------------------------------------------------------------------------------------------- ADA pipe
 
@@ -397,6 +589,6 @@ def gen_augment():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks", "biggan", "augment"]
+    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks", "biggan", "augment", "sg2attent", "host_step"]
     for name in which:
         globals()["gen_" + name]()

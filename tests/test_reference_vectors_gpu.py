@@ -1,0 +1,262 @@
+"""The HIP path against vectors captured from the REFERENCE itself (tests/golden/*.npz, written by tests/golden/make_golden.py from
+/root/reference on CPU) -- no oracle in between.
+
+* op fixtures: every case of bias_act.npz, upfirdn2d.npz, conv2d_resample.npz (including the (up, down) = (2, 2) generic fallback) and
+  modulated_conv2d.npz (outputs, first-order gradients and the R1- / path-length-style SECOND-order gradients d2w, d2s);
+* sg2attent.npz: the StyleGAN2 + non-local-attention hybrid of configs/sg2attent.yaml (generators.py:443-445, discriminators.py:297-299),
+  forward + Gmain / Dmain / R1 gradients of every parameter;
+* host_step_*.npz: the package's ``StepEngine.train_iteration`` (phase schedule, lazy-regularisation rescaling, gains, accumulation
+  rounds, nan_to_num, Adam, EMA, reported statistics) against the reference's own loss / regulariser objects driven through its training
+  loop body for three iterations: weights of G, D and G_ema after every iteration.  ``_ppl`` is configs/ffhq_sg2.yaml's schedule
+  (path-length regulariser in a Greg phase: ``autograd.grad(..., ws, create_graph=True)`` then backward through every generator op).
+
+Tolerances: elementwise ops 1e-5 of the tensor's max magnitude; fp32 convolutions (six bf16 MFMA passes, fp32 accumulate) 2e-4, their
+second-order gradients 1e-3; networks as in test_networks_gpu.py; post-step weights: 2e-5 absolute + 2e-3 of the size of the update
+(lr = 2.5e-3; the comparison is on the weight DELTA, so an unchanged weight cannot pass for a correct one).
+"""
+import contextlib
+
+import pytest
+import torch
+
+import style_big_gan_amd  # noqa: F401
+from golden_util import Golden, max_rel
+from style_big_gan_amd.torch_utils.ops import bias_act, conv2d_resample, upfirdn2d
+from style_big_gan_amd.train_parts import discriminators as PD
+from style_big_gan_amd.train_parts import generators as PG
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, tol, what):
+    ref = ref.to(got.device)
+    scale = float(ref.abs().max()) + 1e-12
+    err = float((got.detach().float() - ref).abs().max()) / scale
+    assert err < tol, f"{what}: rel err {err:.3e} >= {tol:g} (scale {scale:.3e})"
+
+
+# ---------------------------------------------------------------------------------------------------------------- op fixtures
+
+def test_bias_act_reference_vectors(dev):
+    g = Golden("bias_act")
+    for case in g.meta["cases"]:
+        k = case["key"]
+        x = g.t(f"{k}/x").to(dev).requires_grad_(True)
+        b = g.t(f"{k}/b").to(dev).requires_grad_(True) if case["use_b"] else None
+        dy = g.t(f"{k}/dy").to(dev).requires_grad_(True)
+        y = bias_act.bias_act(x, b, dim=1, act=case["act"], clamp=case["clamp"], gain=case["gain"])
+        _close(y, g.t(f"{k}/y"), 1e-5, f"{case} y")
+        grads = torch.autograd.grad((y * dy).sum(), [x] + ([b] if b is not None else []), create_graph=True)
+        _close(grads[0], g.t(f"{k}/dx"), 1e-5, f"{case} dx")
+        if b is not None:
+            _close(grads[1], g.t(f"{k}/db"), 1e-5, f"{case} db")
+        g2 = torch.autograd.grad((grads[0] * g.t(f"{k}/v").to(dev)).sum(), [dy, x], allow_unused=True)
+        _close(g2[0], g.t(f"{k}/d_dy"), 1e-5, f"{case} d_dy")
+        if f"{k}/d_x" in g:
+            got = g2[1] if g2[1] is not None else torch.zeros_like(x)
+            _close(got, g.t(f"{k}/d_x"), 1e-5, f"{case} d_x")
+
+
+def test_upfirdn2d_reference_vectors(dev):
+    g = Golden("upfirdn2d")
+    filters = {name: (g.t(f"f/{name}").to(dev) if f"f/{name}" in g else None) for name in ["k4", "sym6", "none", "k4_flipped_gain2"]}
+    for case in g.meta["cases"]:
+        k = case["key"]
+        x = g.t(f"{k}/x").to(dev).requires_grad_(True)
+        dy = g.t(f"{k}/dy").to(dev).requires_grad_(True)
+        y = upfirdn2d.upfirdn2d(x, filters[case["filter"]], up=case["up"], down=case["down"], padding=case["padding"],
+                                flip_filter=case["flip_filter"], gain=case["gain"])
+        _close(y, g.t(f"{k}/y"), 1e-5, f"{case} y")
+        (dx,) = torch.autograd.grad((y * dy).sum(), x, create_graph=True)
+        _close(dx, g.t(f"{k}/dx"), 1e-5, f"{case} dx")
+        (ddy,) = torch.autograd.grad((dx * g.t(f"{k}/v").to(dev)).sum(), dy)
+        _close(ddy, g.t(f"{k}/ddy"), 1e-5, f"{case} ddy")
+
+
+def test_conv2d_resample_reference_vectors(dev):
+    g = Golden("conv2d_resample")
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+    seen = set()
+    for case in g.meta["cases"]:
+        k = case["key"]
+        x = g.t(f"{k}/x").to(dev).requires_grad_(True)
+        w = g.t(f"{k}/w").to(dev).requires_grad_(True)
+        y = conv2d_resample.conv2d_resample(x, w, f=f, up=case["up"], down=case["down"], padding=case["k"] // 2, groups=case["groups"],
+                                            flip_weight=case["flip_weight"])
+        _close(y, g.t(f"{k}/y"), 2e-4, f"{case} y")
+        dx, dw = torch.autograd.grad((y * g.t(f"{k}/dy").to(dev)).sum(), [x, w])
+        _close(dx, g.t(f"{k}/dx"), 2e-4, f"{case} dx")
+        _close(dw, g.t(f"{k}/dw"), 2e-4, f"{case} dw")
+        seen.add((case["up"], case["down"]))
+    assert (2, 2) in seen        # the generic fallback (reference conv2d_resample.py:150-154) is part of the fixture
+
+
+def test_modulated_conv2d_reference_vectors(dev):
+    """demodulate x fused_modconv x up x noise: y, dx, dw, ds and the second-order d2w, d2s of |ds|^2 + |dx|^2 (the pattern of the
+    path-length and R1 regularisers) -- through scale_nc / demodulation / (transposed) conv / low-pass, all differentiated twice"""
+    g = Golden("modulated_conv2d")
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+    assert len(g.meta["cases"]) == 16
+    for case in g.meta["cases"]:
+        k = case["key"]
+        x, w, s = [g.t(f"{k}/{n}").to(dev).requires_grad_(True) for n in ("x", "w", "s")]
+        noise = g.t(f"{k}/noise").to(dev) if case["use_noise"] else None
+        y = PG.modulated_conv2d(x=x, weight=w, styles=s, noise=noise, up=case["up"], padding=1, resample_filter=f, demodulate=case["demodulate"],
+                                flip_weight=(case["up"] == 1), fused_modconv=case["fused_modconv"])
+        _close(y, g.t(f"{k}/y"), 2e-4, f"{case} y")
+        grads = torch.autograd.grad((y * g.t(f"{k}/dy").to(dev)).sum(), [x, w, s], create_graph=True)
+        for got, name in zip(grads, ("dx", "dw", "ds")):
+            _close(got, g.t(f"{k}/{name}"), 2e-4, f"{case} {name}")
+        d2w, d2s = torch.autograd.grad(grads[2].square().sum() + grads[0].square().sum(), [w, s])
+        _close(d2w, g.t(f"{k}/d2w"), 1e-3, f"{case} d2w")
+        _close(d2s, g.t(f"{k}/d2s"), 1e-3, f"{case} d2s")
+
+
+# ---------------------------------------------------------------------------------------------------------------- sg2attent
+
+def _check_grads(module, g, prefix, tol):
+    bad = []
+    for name, p in module.named_parameters():
+        ref = g.t(prefix + name)
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        err = max_rel(got, ref)
+        if err >= tol and float(ref.abs().max()) >= 1e-7:
+            bad.append((name, err))
+    assert not bad, f"{prefix}: {bad}"
+
+
+def test_sg2_attention_hybrid(dev):
+    import torch.nn.functional as F
+    from style_big_gan_amd.biggan.layers import Attention
+    from style_big_gan_amd.torch_utils.ops import conv2d_gradfix
+    g = Golden("sg2attent")
+    G = PG.generators["sg2_classic"](**g.meta["g_kwargs"])
+    D = PD.discriminators["sg2_classic"](**g.meta["d_kwargs"])
+    assert sum(isinstance(m, Attention) for m in G.modules()) == 3 and sum(isinstance(m, Attention) for m in D.modules()) == 2
+    G.load_state_dict(g.state_dict("G"), strict=True)
+    D.load_state_dict(g.state_dict("D"), strict=True)
+    G, D = G.to(dev).train(), D.to(dev).train()
+    z, z2, real = g.t("z").to(dev), g.t("z2").to(dev), g.t("real").to(dev)
+    c = torch.zeros(z.shape[0], 0, device=dev)
+    # Gmain (the forwards run in the fixture's order: every spectral-norm layer advances its power iteration once per forward)
+    G.requires_grad_(True); D.requires_grad_(False)
+    ws = G.mapping(z, c, skip_w_avg_update=True)
+    _close(ws, g.t("ws"), 1e-5, "ws")
+    img = G.synthesis(ws, noise_mode="const")
+    _close(img, g.t("img"), 1e-4, "img")
+    logits = D(img, c)
+    _close(logits, g.t("logits"), 2e-4, "logits")
+    loss_g = F.softplus(-logits).mean()
+    loss_g.backward()
+    assert abs(float(loss_g) - float(g.t("loss_g"))) < 1e-4
+    _check_grads(G, g, "gradG/", 1e-3)
+    for key in g.keys("G_after/"):
+        _close(G.state_dict()[key[len("G_after/"):]], g.t(key), 1e-4, key)
+    # Dmain
+    G.requires_grad_(False); D.requires_grad_(True)
+    with torch.no_grad():
+        fake = G.synthesis(G.mapping(z2, c, skip_w_avg_update=True), noise_mode="const")
+    real_in = real.clone().requires_grad_(True)
+    real_logits = D(real_in, c)
+    _close(real_logits, g.t("real_logits"), 2e-4, "real_logits")
+    loss_d = F.softplus(-real_logits).mean() + F.softplus(D(fake, c)).mean()
+    loss_d.backward(retain_graph=True)
+    assert abs(float(loss_d) - float(g.t("loss_d"))) < 1e-4
+    _check_grads(D, g, "gradD/", 1e-3)
+    for p in D.parameters():
+        p.grad = None
+    # R1: double backward through the attention blocks (spectral-norm 1x1 convs, max-pool, softmax map) as well
+    with conv2d_gradfix.no_weight_gradients():
+        (r1,) = torch.autograd.grad(real_logits.sum(), real_in, create_graph=True)
+    pen = (r1.square().sum([1, 2, 3]) * (g.meta["r1_gamma"] / 2)).mean()
+    pen.backward()
+    assert abs(float(pen) - float(g.t("r1_penalty"))) < 2e-3 * max(1.0, abs(float(g.t("r1_penalty"))))
+    _check_grads(D, g, "gradR1/", 4e-3)
+
+
+def test_sg2_attention_hybrid_bf16(dev):
+    """the same hybrid with every block in bf16 (attention itself runs in fp32 inside the block, reference :443-445)"""
+    g = Golden("sg2attent")
+    gk, dk = dict(g.meta["g_kwargs"]), dict(g.meta["d_kwargs"])
+    gk["synthesis_kwargs"] = dict(gk["synthesis_kwargs"], num_fp16_res=8)
+    dk["num_fp16_res"] = 8
+    G = PG.generators["sg2_classic"](**gk); D = PD.discriminators["sg2_classic"](**dk)
+    G.load_state_dict(g.state_dict("G"), strict=True); D.load_state_dict(g.state_dict("D"), strict=True)
+    G, D = G.to(dev).train(), D.to(dev).train()
+    c = torch.zeros(4, 0, device=dev)
+    with torch.no_grad():
+        img = G.synthesis(G.mapping(g.t("z").to(dev), c, skip_w_avg_update=True), noise_mode="const")
+        assert max_rel(img, g.t("img")) < 6e-2
+        assert max_rel(D(g.t("img").to(dev), c), g.t("logits")) < 6e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------- host step
+
+@contextlib.contextmanager
+def _scripted_randn_like(tensors):
+    """hand out the recorded path-length directions in order (the only ``randn_like`` on the step's path); anything else would exhaust it"""
+    real, queue = torch.randn_like, list(tensors)
+
+    def scripted(t, *a, **k):
+        assert queue, "more randn_like draws than the reference made"
+        out = queue.pop(0).to(t.device)
+        assert out.shape == t.shape
+        return out
+
+    torch.randn_like = scripted
+    try:
+        yield queue
+    finally:
+        torch.randn_like = real
+
+
+@pytest.mark.parametrize("tag", ["r1", "ppl"])
+def test_step_engine_against_reference_schedule(dev, tag):
+    from style_big_gan_amd.torch_utils import training_stats
+    from style_big_gan_amd.train_parts import trainers
+    g = Golden("host_step_" + tag)
+    cfg = g.meta["cfg"]
+    eng = trainers.StepEngine(dev, gen_kwargs=cfg["g_kwargs"], disc_kwargs=cfg["d_kwargs"], loss_arch="sg2", loss=cfg["loss"],
+                              loss_arch_kwargs=dict(style_mixing_prob=0), gen_regs=[tuple(r) for r in cfg["gen_regs"]],
+                              dis_regs=[tuple(r) for r in cfg["dis_regs"]], optim_gen=("adam", cfg["opt"]), optim_disc=("adam", cfg["opt"]),
+                              g_reg_interval=cfg["g_reg_interval"], d_reg_interval=cfg["d_reg_interval"], batch=cfg["batch"],
+                              batch_gpu=cfg["batch_gpu"], ema_kimg=cfg["ema_kimg"], ema_rampup=cfg["ema_rampup"])
+    try:
+        assert [(p.name, p.interval) for p in eng.phases] == [(s["name"], s["interval"]) for s in g.meta["slots"]]
+        eng.G.load_state_dict(g.state_dict("G0"), strict=True)
+        eng.D.load_state_dict(g.state_dict("D0"), strict=True)
+        eng.G_ema.load_state_dict(g.state_dict("G0"), strict=True)
+        # the fixture pins the synthesis network with its registered constant noise (see make_golden._ConstNoise)
+        syn_forward = eng.G.synthesis.forward
+        eng.G.synthesis.forward = lambda ws, **kw: syn_forward(ws, noise_mode="const", **kw)
+        collector = training_stats.Collector(regex="Loss/.*")
+        collector.update()
+        prev = {"G": g.state_dict("G0"), "D": g.state_dict("D0"), "G_ema": g.state_dict("G0")}
+        pl_noise = [g.t(f"pl_noise/{i}") for i in range(g.meta["n_pl_noise"])]
+        with _scripted_randn_like(pl_noise) as left:
+            for it in range(cfg["iterations"]):
+                eng.train_iteration(g.t(f"it{it}/real").to(dev), None, all_gen_z=g.t(f"it{it}/all_gen_z").to(dev))
+                for net, module in (("G", eng.G), ("D", eng.D), ("G_ema", eng.G_ema)):
+                    ref = g.state_dict(f"it{it}/{net}")
+                    got = module.state_dict()
+                    assert set(got) == set(ref)
+                    moved = 0.0
+                    for k in ref:
+                        delta_ref = ref[k] - prev[net][k]
+                        delta_got = got[k].detach().float().cpu() - prev[net][k]
+                        tol = 2e-5 + 2e-3 * float(delta_ref.abs().max())
+                        err = float((delta_got - delta_ref).abs().max())
+                        assert err <= tol, f"{tag} iteration {it} {net}.{k}: |delta - reference delta| = {err:.3e} > {tol:.3e}"
+                        moved = max(moved, float(delta_ref.abs().max()))
+                    assert moved > 0
+                    prev[net] = ref
+        assert not left, "fewer randn_like draws than the reference made"
+        assert eng.cur_nimg == cfg["iterations"] * cfg["batch"] and eng.batch_idx == cfg["iterations"]
+        if tag == "ppl":
+            _close(eng.loss.gen_regs[0].pl_mean, g.t("pl_mean"), 1e-3, "pl_mean")
+        collector.update()
+        for name, ref in g.meta["stats"].items():
+            assert collector.num(name) == ref["num"], (name, collector.num(name), ref["num"])
+            assert abs(collector.mean(name) - ref["mean"]) < 2e-3 * max(1.0, abs(ref["mean"])), (name, collector.mean(name), ref["mean"])
+    finally:
+        eng.close()
