@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of the StyleGAN2-ADA G+D training step at 256x256, bf16, on N MI355X.
+"""Benchmark of the G+D training step on N MI355X.  Headline: images/sec of StyleGAN2-ADA at 256x256, bf16.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--workload sg2ada|ffhq_sg2|sg2attent|big_gan]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one iteration of the reference's training loop body (train_parts/trainers.py:711-765) on synthetic inputs:
-phases Gmain and Dmain every iteration and Dreg (R1, lazy, gain 4) every 4th, each phase = zero_grad -> accumulation rounds of
-forward/backward -> gradient all-reduce -> nan_to_num -> Adam, then the G_ema update.  Workload = configs/sg2ada.yaml at
-256x256: z = w = 512, 2 mapping layers, channel_base 32768, D architecture 'orig', mbstd group 32, softplus loss, R1 gamma 0.01,
-style mixing 0, batch 64 per rank as 2 rounds of batch_gpu 32 (weak scaling: the global batch is 64 x N), every block from 8x8
-up in bf16 (num_fp16_res = 7, conv_clamp = 256 -- the reference's mixed-precision recipe with bf16 in place of fp16), ADA off.
-Latents ~ N(0, 1), reals uint8 U[0, 255] generated on the device once; random-init weights (no network for datasets).
+A "step" is one iteration of the reference's training loop body (train_parts/trainers.py:711-765) on synthetic inputs: every phase
+that is due (Gmain / Dmain each iteration, lazy regularisers every `interval`-th), each phase = zero_grad -> accumulation rounds of
+forward/backward -> gradient all-reduce -> nan_to_num -> Adam, then the G_ema update.  The timed region starts on an iteration on
+which every phase is due.  Latents ~ N(0, 1), reals uint8 U[0, 255] generated on the device once, uniformly drawn one-hot labels
+for the class-conditional workload; random-init weights (no network for datasets or checkpoints).
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).  `roofline` is measured live: the library
-brackets every kernel launch of the timed region with hipEvents on the launch stream (sbg_prof_*), and the dominant kernel's
-algorithmic flops / summed duration is reported against the dense bf16 MFMA peak.  `cpu_baseline` times the CPU oracle
-(oracle/, the fixture-pinned restatement of the reference's eager CPU path) on a bounded sample of the same workload.
+Workloads (BASELINE.json `configs`; the default is the one the metric is quoted on):
+  sg2ada     configs/sg2ada.yaml @ 256x256: z = w = 512, 2 mapping layers, channel_base 32768, D 'orig', mbstd 32, softplus + R1(0.01)/4,
+             a (regulariser-less) Greg slot every 16 -- i.e. G's Adam runs at lr * 16/17 --, batch 64 = 2 x batch_gpu 32, ADA off
+  ffhq_sg2   configs/ffhq_sg2.yaml @ 1024x1024: 6 mapping layers, channel_base 16384, D 'resnet', mbstd 8, R1(1)/4 + path length(2, shrink 2)/16
+  sg2attent  configs/sg2attent.yaml @ 32x32 (the yaml's data; --res 256 for the SURVEY's second size): G attention at 32/16/8/4, D at 32
+  big_gan    configs/big_gan.yaml @ 128x128: class-conditional BigGAN (10 classes), hinge, n_dis 4, D attention at 32, batch 48 (the yaml's
+             50 is not divisible by 8 ranks), cross-replica batch norm when N > 1
+In the StyleGAN2 workloads every block from 8x8 up runs in bf16 with conv_clamp 256 (the reference's mixed-precision recipe with bf16 in
+place of fp16, applied to more blocks than its default num_fp16_res = 4); BigGAN runs in fp32 storage (convolutions as split-bf16 MFMA).
+
+--scaling weak (default): the per-rank batch is fixed, the global batch is batch x N.  --scaling strong: the GLOBAL batch is fixed at the
+config's value and each rank takes batch // N of it in rounds of min(batch_gpu, batch // N) -- the reference's own partitioning
+(trainers.py:524,737).
+
+Prints ONE JSON line on rank 0 (README / DESIGN.md explain the fields).  `roofline` is measured live: the library brackets every kernel
+launch of the timed region with hipEvents on the launch stream (sbg_prof_*), and the dominant kernel kind's algorithmic flops / summed
+duration is reported against the dense bf16 MFMA peak.  `cpu_baseline` times the CPU oracle (oracle/, the fixture-pinned restatement of
+the reference's eager CPU path) on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -32,26 +44,68 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense, /opt/skills/guides/MI355X_MICROARCH
 HBM_PEAK_GBS = 8000.0
 
 RES, Z_DIM, BATCH, BATCH_GPU = 256, 512, 64, 32
+ADAM = dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)
 
 
-def sg2ada_kwargs(res=RES, num_fp16_res=7, conv_clamp=256, channel_base=32768, mbstd=32):
-    gk = dict(z_dim=Z_DIM, c_dim=0, w_dim=512, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=2),
-              synthesis_kwargs=dict(channel_base=channel_base, num_fp16_res=num_fp16_res, block_kwargs=dict(conv_clamp=conv_clamp)))
-    dk = dict(c_dim=0, img_resolution=res, img_channels=3, architecture='orig', channel_base=channel_base, num_fp16_res=num_fp16_res,
+def _bf16_blocks(res):
+    """num_fp16_res that puts every block from 8x8 up in reduced precision"""
+    return max(res.bit_length() - 3, 0)
+
+
+def sg2ada_kwargs(res=RES, num_fp16_res=None, conv_clamp=256, channel_base=32768, mbstd=32, mapping_layers=2, d_arch='orig', attn_g=(), attn_d=()):
+    nfp = _bf16_blocks(res) if num_fp16_res is None else num_fp16_res
+    gk = dict(z_dim=Z_DIM, c_dim=0, w_dim=512, img_resolution=res, img_channels=3, attentions=list(attn_g), mapping_kwargs=dict(num_layers=mapping_layers),
+              synthesis_kwargs=dict(channel_base=channel_base, num_fp16_res=nfp, block_kwargs=dict(conv_clamp=conv_clamp)))
+    dk = dict(c_dim=0, img_resolution=res, img_channels=3, attentions=list(attn_d), architecture=d_arch, channel_base=channel_base, num_fp16_res=nfp,
               conv_clamp=conv_clamp, epilogue_kwargs=dict(mbstd_group_size=mbstd))
     return gk, dk
 
 
-def build_engine(device, world_size, rank, batch=BATCH, batch_gpu=BATCH_GPU, res=RES, ada=None):
+def workload(name, res=None):
+    """-> dict(res, batch, batch_gpu, c_dim, dtype, label, steps (default K), engine (StepEngine keywords))"""
+    sg2 = dict(generator='sg2_classic', discriminator='sg2_classic', loss_arch='sg2', loss='softplus', loss_arch_kwargs=dict(style_mixing_prob=0),
+               optim_gen=('adam', dict(ADAM)), optim_disc=('adam', dict(ADAM)))
+    if name == 'sg2ada':
+        res = res or 256
+        gk, dk = sg2ada_kwargs(res=res)
+        return dict(res=res, batch=64, batch_gpu=32, c_dim=0, dtype='bf16', steps=8,
+                    label=f'configs/sg2ada.yaml @ {res}x{res}: sg2_classic G (skip) + D (orig), softplus + R1(0.01)/4, idle Greg slot /16 (G lr x 16/17)',
+                    engine=dict(sg2, gen_kwargs=gk, disc_kwargs=dk, gen_regs=[], dis_regs=[('r1', dict(r1_gamma=0.01))], g_reg_interval=16,
+                                d_reg_interval=4, ema_kimg=500, ema_rampup=0.05))
+    if name == 'ffhq_sg2':
+        res = res or 1024
+        gk, dk = sg2ada_kwargs(res=res, channel_base=16384, mbstd=8, mapping_layers=6, d_arch='resnet')
+        return dict(res=res, batch=64, batch_gpu=32, c_dim=0, dtype='bf16', steps=16,
+                    label=f'configs/ffhq_sg2.yaml @ {res}x{res}: channel_base 16384, 6 mapping layers, D resnet, softplus + R1(1)/4 + path length(weight 2, shrink 2)/16',
+                    engine=dict(sg2, gen_kwargs=gk, disc_kwargs=dk, gen_regs=[('ppl', dict(pl_batch_shrink=2, pl_decay=0.01, pl_weight=2.))],
+                                dis_regs=[('r1', dict(r1_gamma=1.))], g_reg_interval=16, d_reg_interval=4, ema_kimg=20, ema_rampup=None))
+    if name == 'sg2attent':
+        res = res or 32
+        gk, dk = sg2ada_kwargs(res=res, attn_g=[32, 16, 8, 4], attn_d=[32])
+        return dict(res=res, batch=64, batch_gpu=64, c_dim=0, dtype='bf16', steps=8,
+                    label=f'configs/sg2attent.yaml @ {res}x{res}: sg2_classic + non-local attention (G at 32/16/8/4, D at 32), softplus + R1(0.01)/4',
+                    engine=dict(sg2, gen_kwargs=gk, disc_kwargs=dk, gen_regs=[], dis_regs=[('r1', dict(r1_gamma=0.01))], g_reg_interval=16,
+                                d_reg_interval=4, ema_kimg=500, ema_rampup=0.05))
+    if name == 'big_gan':
+        res = res or 128
+        opt = dict(lr=0.0002, betas=[0.0, 0.999], eps=1e-8)
+        return dict(res=res, batch=48, batch_gpu=48, c_dim=10, dtype='f32', steps=8,
+                    label=f'configs/big_gan.yaml @ {res}x{res}: BigGAN G (ch 64, no attention) + D (ch 64, attention at 32), 10 classes, hinge, n_dis 4 '
+                          '(G phase every 4th step, gain 4), batch 48 in place of 50',
+                    engine=dict(generator='big_gan', discriminator='big_gan', loss_arch='base', loss='hinge', loss_arch_kwargs=dict(),
+                                gen_kwargs=dict(c_dim=10, img_resolution=res, G_shared=False, G_attn='0', G_init='N02', n_classes=10),
+                                disc_kwargs=dict(c_dim=10, img_resolution=res, D_attn='32', D_init='N02', n_classes=10),
+                                optim_gen=('adam', opt), optim_disc=('adam', dict(opt)), gen_regs=[], dis_regs=[], g_reg_interval=0, d_reg_interval=0,
+                                n_dis=4, ema_kimg=500, ema_rampup=None))
+    raise SystemExit(f'unknown workload {name}')
+
+
+def build_engine(device, world_size, rank, wl, batch, batch_gpu, ada=None):
     from style_big_gan_amd.train_parts import trainers
-    gk, dk = sg2ada_kwargs(res=res)
-    return trainers.StepEngine(device, generator='sg2_classic', discriminator='sg2_classic', gen_kwargs=gk, disc_kwargs=dk,
-                               loss_arch='sg2', loss='softplus', loss_arch_kwargs=dict(style_mixing_prob=0),
-                               gen_regs=[], dis_regs=[('r1', dict(r1_gamma=0.01))],
-                               optim_gen=('adam', dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)),
-                               optim_disc=('adam', dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)),
-                               g_reg_interval=16, d_reg_interval=4, batch=batch, batch_gpu=batch_gpu,
-                               ema_kimg=500, ema_rampup=0.05, world_size=world_size, rank=rank, seed=0, **ada_kwargs(ada))
+    kw = dict(wl['engine'])
+    if wl['engine']['generator'] == 'big_gan' and world_size > 1:
+        kw['gen_kwargs'] = dict(kw['gen_kwargs'], cross_replica=True)      # synchronised batch norm over the ranks (reference layers.py:297-298)
+    return trainers.StepEngine(device, batch=batch, batch_gpu=batch_gpu, world_size=world_size, rank=rank, seed=0, **kw, **ada_kwargs(ada))
 
 
 def ada_kwargs(ada):
@@ -73,7 +127,7 @@ def summarize_kernels(records):
 
 
 # kernel kind of the launch log -> kernel names in the rocprofv3 traces
-PMC_KERNELS = {'conv_igemm': ('conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel'),
+PMC_KERNELS = {'conv_igemm': ('conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel', 'conv_up_fir_kernel'),
                'conv_wgrad': ('conv_wgrad_rows_kernel', 'conv_wgrad_kernel'), 'upfirdn2d': ('upfirdn2d_fir', 'upfirdn2d_kernel'),
                'bias_act': ('bias_act',), 'scale_nc': ('scale_nc',), 'dot_hw': ('dot_hw',)}
 
@@ -98,7 +152,7 @@ def pmc_traffic(kind):
 
 
 def cpu_baseline(sample_batch=2, res=RES):
-    """One Gmain + Dmain + Dreg pass of the CPU oracle on `sample_batch` images at the benchmark's shapes (fp32, all host
+    """One Gmain + Dmain + Dreg pass of the CPU oracle on `sample_batch` images at the headline workload's shapes (fp32, all host
     threads); returns img/s of a G+D step with Dreg amortised over 4 iterations, like the GPU figure."""
     from oracle import networks as ON
     from style_big_gan_amd.train_parts import discriminators, generators
@@ -117,8 +171,7 @@ def cpu_baseline(sample_batch=2, res=RES):
     ON.gd_step_grads(gsd, dsd, cfg, z_g, z_d, real, r1_gamma=None, noise_mode='const')         # Gmain + Dmain
     t_main = time.perf_counter() - t0
     t0 = time.perf_counter()
-    import torch.nn.functional as F     # Dreg alone: D forward on reals, R1 double backward
-    d_leaf = {k: v.clone().requires_grad_('resample' not in k) for k, v in dsd.items()}
+    d_leaf = {k: v.clone().requires_grad_('resample' not in k) for k, v in dsd.items()}      # Dreg alone: D forward on reals, R1 double backward
     real_in = real.clone().requires_grad_(True)
     logits = ON.discriminator(d_leaf, real_in, torch.zeros(n, 0), cfg)
     r1 = torch.autograd.grad(logits.sum(), real_in, create_graph=True)[0]
@@ -128,20 +181,24 @@ def cpu_baseline(sample_batch=2, res=RES):
     sec_per_img = (t_main + t_reg / 4) / n
     return dict(value=round(1.0 / sec_per_img, 4), unit='img/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'oracle/ (CPU restatement of the reference eager path, fp32), one Gmain+Dmain ({t_main:.1f}s) + one Dreg ({t_reg:.1f}s, /4) '
-                       f'on batch {n} at {res}x{res}, sg2ada shapes')
+                       f'on batch {n} at {res}x{res}, sg2ada shapes; at batch 2 the path does not scale with threads -- the reference proper, '
+                       'imported in the build container, ran the same passes at 0.18 img/s on 8 cores (BASELINE.md section 3)')
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--workload', default='sg2ada', choices=['sg2ada', 'ffhq_sg2', 'sg2attent', 'big_gan'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--res', type=int, default=RES, help='debug only; the benchmark is 256')
-    ap.add_argument('--batch', type=int, default=BATCH)
-    ap.add_argument('--batch-gpu', type=int, default=BATCH_GPU)
+    ap.add_argument('--res', type=int, default=None, help='resolution override (sg2attent: 32 or 256; otherwise debug only)')
+    ap.add_argument('--batch', type=int, default=None, help='per-rank batch (weak) / global batch (strong); default: the config\'s')
+    ap.add_argument('--batch-gpu', type=int, default=None)
     ap.add_argument('--ada', type=float, default=None, metavar='P', help="secondary measurement: 'bgc' ADA pipe on, starting strength P (headline = off)")
     ap.add_argument('--kernel-breakdown', action='store_true', help='print the per-kernel launch log summary to stderr')
+    ap.add_argument('--launch-log', default=None, metavar='FILE', help='write the launch log of the timed region (one JSON record per launch, in launch order)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -158,16 +215,32 @@ def main():
         torch.distributed.init_process_group(backend, **(dict(device_id=device) if backend == 'nccl' else {}))
     assert world == args.gpus or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
 
-    import style_big_gan_amd
+    wl = workload(args.workload, args.res)
+    res = wl['res']
+    steps = args.steps if args.steps is not None else wl['steps']
+    cfg_batch = args.batch or wl['batch']
+    if args.scaling == 'strong':
+        assert cfg_batch % world == 0, f'strong scaling: global batch {cfg_batch} is not divisible by {world} ranks'
+        batch = cfg_batch // world                                   # reference trainers.py:524
+        global_batch = cfg_batch
+    else:
+        batch, global_batch = cfg_batch, cfg_batch * world
+    batch_gpu = min(args.batch_gpu or wl['batch_gpu'], batch)      # reference trainers.py:203-204
+    assert batch % batch_gpu == 0
+
+    import style_big_gan_amd  # noqa: F401
     from style_big_gan_amd import _lib
     _lib.load()
-    eng = build_engine(device, world, rank, batch=args.batch, batch_gpu=args.batch_gpu, res=args.res, ada=args.ada)
+    eng = build_engine(device, world, rank, wl, batch=batch, batch_gpu=batch_gpu, ada=args.ada)
     gen = torch.Generator(device=device); gen.manual_seed(1234 + rank)
-    real_u8 = torch.randint(0, 256, [args.batch, 3, args.res, args.res], device=device, dtype=torch.uint8, generator=gen)
+    real_u8 = torch.randint(0, 256, [batch, 3, res, res], device=device, dtype=torch.uint8, generator=gen)
+    real_c = None
+    if wl['c_dim']:
+        real_c = torch.nn.functional.one_hot(torch.randint(0, wl['c_dim'], [batch], device=device, generator=gen), wl['c_dim']).float()
 
     def step():
         real = real_u8.to(torch.float32) / 127.5 - 1
-        eng.train_iteration(real, None)
+        eng.train_iteration(real, real_c)
 
     def barrier():
         if world > 1:
@@ -176,17 +249,21 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.batch_idx = 0       # the timed region starts on an iteration that runs Dreg: K steps contain ceil(K / 4) Dreg phases
+    eng.batch_idx = 0       # the timed region starts on an iteration on which every phase is due: K steps contain ceil(K / interval) of each
     barrier()
     _lib.prof_enable(True)
     _lib.prof_fetch()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step durations (torch's stream = the launch stream)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(steps):
         step()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
     records = _lib.prof_fetch()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -194,6 +271,10 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
+        if args.launch_log:
+            with open(args.launch_log, 'w') as f:
+                for r in records:
+                    f.write(json.dumps(dict(kind=r['kind'], dims=list(r['dims']), ms=round(r['ms'], 6), flops=r['flops'], bytes=r['bytes'])) + '\n')
         kern = summarize_kernels(records)
         dom = max(kern.items(), key=lambda kv: kv[1]['ms'])[0] if kern else None
         roofline = None
@@ -209,21 +290,22 @@ def main():
                 roofline = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                                 frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                                 launches=k['launches'], avg_launch_ms=round(k['ms'] / k['launches'], 4))
-        if roofline is not None:
+        if roofline is not None and args.workload == 'sg2ada':      # the committed PMC passes are of the headline workload
             roofline['traffic'], src = pmc_traffic(dom)
             if src:
                 roofline['traffic_source'] = src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch averaged over the same launches)'
                 roofline['algorithmic_bytes_per_launch'] = round(kern[dom]['bytes'] / kern[dom]['launches'])
         # the 256x256 modulated 3x3 conv (M = N*65536 pixels, Cout 128, K = 9*128): the kernel the 40 % MFMA target names
         tgt = [r for r in records if r['kind'] == 'conv_igemm' and r['dims'][1] == 128 and r['dims'][2] == 128 and r['dims'][3] == 9
-               and r['dims'][0] == args.batch_gpu * args.res * args.res]
+               and r['dims'][0] == batch_gpu * res * res] if args.workload == 'sg2ada' else []
         target = None
         if tgt:
             fl, ms = sum(r['flops'] for r in tgt), sum(r['ms'] for r in tgt)
-            target = dict(shape=f'[{args.batch_gpu},128,{args.res},{args.res}] (*) [128,128,3,3]', launches=len(tgt),
+            target = dict(shape=f'[{batch_gpu},128,{res},{res}] (*) [128,128,3,3]', launches=len(tgt),
                           avg_launch_ms=round(ms / len(tgt), 4), tflops=round(fl / ms / 1e9, 2), mfma_frac=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4))
         total_ms = sum(v['ms'] for v in kern.values())
-        breakdown = {k: dict(launches=v['launches'], ms_per_step=round(v['ms'] / args.steps, 3),
+        total_flops = sum(v['flops'] for v in kern.values())
+        breakdown = {k: dict(launches=v['launches'], ms_per_step=round(v['ms'] / steps, 3),
                              tflops=round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 2), gbs=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1))
                      for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])}
         if args.kernel_breakdown:
@@ -234,24 +316,29 @@ def main():
                 k[0] += 1; k[1] += r['ms']; k[2] += r['flops']; k[3] += r['bytes']
             print('top launches by total time (kind, dims): launches, ms/step, avg us, TFLOP/s, GB/s', file=sys.stderr)
             for (kind, dims), (cnt, ms, fl, by) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:90]:
-                print(f'  {kind:13s} {str(dims):52s} {cnt:5d} {ms / args.steps:8.3f} {ms / cnt * 1e3:9.1f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:8.1f}', file=sys.stderr)
+                print(f'  {kind:13s} {str(dims):52s} {cnt:5d} {ms / steps:8.3f} {ms / cnt * 1e3:9.1f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:8.1f}', file=sys.stderr)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(res=args.res)
-        imgs = args.steps * args.batch * world
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'sg2ada':
+            cpu = cpu_baseline(res=res)
+        imgs = steps * global_batch
+        headline = args.workload == 'sg2ada'
         out = {
-            'metric': 'images/sec (G+D step) StyleGAN2-ADA 256x256 bf16', 'value': round(imgs / elapsed, 2), 'unit': 'img/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'configs/sg2ada.yaml @ {args.res}x{args.res}: sg2_classic G (skip) + D (orig), softplus + R1(0.01)/4, '
-                                   f'batch {args.batch}/rank = {args.batch // args.batch_gpu} x batch_gpu {args.batch_gpu}, num_fp16_res 7 (bf16), conv_clamp 256, '
+            'metric': 'images/sec (G+D step) StyleGAN2-ADA 256x256 bf16' if headline and res == 256 else f'images/sec (G+D step) {args.workload} {res}x{res} {wl["dtype"]}',
+            'value': round(imgs / elapsed, 2), 'unit': 'img/s',
+            'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / steps * 1e3, 2),
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
+            'config': {'workload': f'{wl["label"]}, global batch {global_batch} = {world} rank(s) x {batch // batch_gpu} round(s) x batch_gpu {batch_gpu}, '
+                                   + (f'bf16 from 8x8 up (num_fp16_res {_bf16_blocks(res)}; the reference recipe defaults to 4), conv_clamp 256, ' if wl['dtype'] == 'bf16' else 'fp32 storage, ')
                                    + ('ADA off' if args.ada is None else f'ADA bgc on (p0 = {args.ada}, target 0.6; secondary measurement)'),
-                       'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
+                       'global_batch': global_batch, 'parallelism': f'dp{world}'},
             'roofline': roofline, 'target_kernel': target, 'cpu_baseline': cpu,
+            'ms_per_step_median': round(step_ms[len(step_ms) // 2], 2),
+            'step_tflops': round(total_flops / (elapsed * 1e3) / 1e9, 1),
             'kernel_ms_per_step': {k: v['ms_per_step'] for k, v in breakdown.items()},
             'sbg_kernel_time_frac_of_step': round(total_ms / (elapsed * 1e3), 3),
         }
         print(json.dumps(out))
+    eng.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

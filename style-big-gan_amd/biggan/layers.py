@@ -163,11 +163,19 @@ class _AttentionCore(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         theta, phi, g = ctx.saved_tensors
-        with torch.enable_grad():       # recompute the map with differentiable library ops (keeps double-backward available)
-            ins = [t.detach().requires_grad_(True) for t in (theta, phi, g)]
-            out = _attention_reference(*ins)
-        grads = torch.autograd.grad(out, ins, dout, create_graph=torch.is_grad_enabled())
-        return tuple(grads)
+        if torch.is_grad_enabled():
+            # a regulariser differentiates this gradient again (R1 through D's attention): compose it from differentiable library ops ON
+            # THE SAVED TENSORS THEMSELVES, so that the second-order graph reaches theta / phi / g as well as dout
+            ins = [t if t.requires_grad else t.detach().requires_grad_(True) for t in (theta, phi, g)]
+            with torch.enable_grad():
+                out = _attention_reference(*ins)
+                grads = torch.autograd.grad(out, ins, dout, create_graph=True)
+        else:
+            with torch.enable_grad():
+                ins = [t.detach().requires_grad_(True) for t in (theta, phi, g)]
+                out = _attention_reference(*ins)
+            grads = torch.autograd.grad(out, ins, dout)
+        return tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad))
 
 
 def attention_core(theta, phi, g):
