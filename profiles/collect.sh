@@ -1,21 +1,24 @@
 #!/bin/bash
 # Run on the GPU box from the repo root:  bash profiles/collect.sh <tag>
-# Three rocprofv3 passes over the same bench command (kernel trace + stats; FETCH_SIZE; WRITE_SIZE -- the two TCC counters do
-# not fit one pass, and gpurun refuses --pmc together with API tracing), then profiles/summarize.py condenses them.
+# rocprofv3 passes over the same bench command, each its own run (the TCC counters do not fit one pass, and gpurun refuses --pmc
+# together with API tracing):  (1) kernel trace + stats, with bench.py also writing its launch log (shape of every launch, in order);
+# (2) FETCH_SIZE;  (3) WRITE_SIZE;  (4) SQ / GRBM counters: matrix-pipe busy cycles, wave cycles, LDS bank conflicts.
+# profiles/summarize.py condenses them into the files committed under profiles/.  Any failing pass fails the script.
 set -e
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+CMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- $CMD --launch-log $OUT/launch_log.jsonl > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 echo "stats pass done"
-# the PMC passes run under a time limit: a counter-collection failure of the profiler must not hang the box (the summary then lacks traffic)
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o $TAG --output-format csv -- $CMD > /dev/null 2> $OUT/fetch.log || echo "FETCH_SIZE pass failed: $(tail -2 $OUT/fetch.log)"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o $TAG --output-format csv -- $CMD > /dev/null 2> $OUT/fetch.log
 echo "fetch pass done"
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o $TAG --output-format csv -- $CMD > /dev/null 2> $OUT/write.log || echo "WRITE_SIZE pass failed: $(tail -2 $OUT/write.log)"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o $TAG --output-format csv -- $CMD > /dev/null 2> $OUT/write.log
 echo "write pass done"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $OUT/sq -o $TAG --output-format csv -- $CMD --launch-log $OUT/launch_log_sq.jsonl > /dev/null 2> $OUT/sq.log
+echo "sq pass done"
 python3 profiles/summarize.py $OUT $TAG
 # keep only the condensed files in gpurun_out (the raw traces exceed what gpurun merges back)
-mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* gpurun_out/profiles_out/ && rm -rf $OUT
+mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* gpurun_out/profiles_out/ && cp $OUT/*.log gpurun_out/profiles_out/ && rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq

@@ -154,6 +154,70 @@ def _engine_worker(rank, world, init_file, results):
         dist.destroy_process_group()
 
 
+def _syncbn_worker(rank, world, init_file, results):
+    """cross-replica batch norm over two ranks (reference sync_batchnorm/batchnorm.py:120-158: all-reduce of [sum x, sum x^2, n], mean /
+    biased variance for the normalisation, UNBIASED variance into the running buffer; backward all-reduces the statistics' gradients)
+    against one process normalising the concatenated batch with plain autograd: outputs, running statistics, gradients w.r.t. the rank's
+    own slice of the input and w.r.t. gain / bias."""
+    sys.path.insert(0, ROOT)
+    import style_big_gan_amd  # noqa: F401
+    from style_big_gan_amd.biggan import layers
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(11)
+        x_all = torch.randn(world * 3, 5, 4, 4, dtype=torch.float64).float() * 2 + 0.5      # both ranks draw the same full batch ...
+        w_all = torch.randn(world * 3, 5, 4, 4)
+        gain0, bias0 = torch.rand(5) + 0.5, torch.randn(5)
+        sl = slice(rank * 3, (rank + 1) * 3)                                                  # ... and own one slice of it
+        x = x_all[sl].clone().requires_grad_(True)
+        mod = layers.bn(5, cross_replica=True).train()
+        with torch.no_grad():
+            mod.gain.copy_(gain0); mod.bias.copy_(bias0)
+        y = mod(x)
+        (y * w_all[sl]).sum().backward()
+
+        # single-process statement over the whole batch
+        xr = x_all.clone().requires_grad_(True)
+        g, b = gain0.clone().requires_grad_(True), bias0.clone().requires_grad_(True)
+        n = xr.numel() / xr.shape[1]
+        mean = xr.sum([0, 2, 3]) / n
+        sumvar = xr.square().sum([0, 2, 3]) - xr.sum([0, 2, 3]) * mean
+        inv_std = torch.rsqrt(sumvar / n + mod.eps)
+        yr = (xr - mean.view(1, -1, 1, 1)) * (inv_std * g).view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+        (yr * w_all).sum().backward()
+        assert torch.allclose(y, yr[sl].detach(), atol=1e-5), "normalised output differs from the whole-batch statement"
+        assert torch.allclose(x.grad, xr.grad[sl], atol=1e-5), "input gradient differs (the statistics' gradients must be all-reduced)"
+        # gain / bias gradients are per-rank partial sums (the trainer's GradReducer averages them like every other parameter)
+        for got, ref in ((mod.gain.grad, g.grad), (mod.bias.grad, b.grad)):
+            tot = got.clone(); dist.all_reduce(tot)
+            assert torch.allclose(tot, ref, atol=1e-4)
+        assert torch.allclose(mod.stored_mean, 0.1 * mean.detach(), atol=1e-6)
+        assert torch.allclose(mod.stored_var, 0.9 + 0.1 * (sumvar / (n - 1)).detach(), atol=1e-5)          # unbiased variance (:153,157)
+        # both ranks hold the same running statistics
+        both = [torch.zeros_like(mod.stored_var) for _ in range(world)]
+        dist.all_gather(both, mod.stored_var)
+        assert torch.equal(both[0], both[1])
+
+        # class-conditional variant with per-sample gain / bias (what BigGAN's generator uses)
+        cc = layers.ccbn(5, 7, torch.nn.Embedding, cross_replica=True).train()
+        for p_ in cc.parameters():
+            dist.broadcast(p_.detach(), src=0)
+        labels = torch.tensor([1, 3, 3, 6, 0, 2])
+        x2 = x_all[sl].clone().requires_grad_(True)
+        y2 = cc(x2, labels[sl])
+        (y2 * w_all[sl]).sum().backward()
+        xr2 = x_all.clone().requires_grad_(True)
+        gain = (1 + cc.gain(labels)).detach().view(-1, 5, 1, 1); bias = cc.bias(labels).detach().view(-1, 5, 1, 1)
+        mean = xr2.sum([0, 2, 3]) / n
+        inv_std = torch.rsqrt((xr2.square().sum([0, 2, 3]) - xr2.sum([0, 2, 3]) * mean) / n + cc.eps)
+        yr2 = (xr2 - mean.view(1, -1, 1, 1)) * inv_std.view(1, -1, 1, 1) * gain + bias
+        (yr2 * w_all).sum().backward()
+        assert torch.allclose(y2, yr2[sl].detach(), atol=1e-5) and torch.allclose(x2.grad, xr2.grad[sl], atol=1e-5)
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
 def _run_world(target, world=2):
     with tempfile.TemporaryDirectory() as d:
         init_file = os.path.join(d, "rdzv")
@@ -176,6 +240,10 @@ def test_grad_reducer_world2_gloo():
 
 def test_step_engine_world2_repeated_sync_and_ema():
     _run_world(_engine_worker)
+
+
+def test_cross_replica_batch_norm_world2():
+    _run_world(_syncbn_worker)
 
 
 def test_grad_reducer_single_process():
