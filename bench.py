@@ -198,6 +198,8 @@ def main():
     ap.add_argument('--batch-gpu', type=int, default=None)
     ap.add_argument('--ada', type=float, default=None, metavar='P', help="secondary measurement: 'bgc' ADA pipe on, starting strength P (headline = off)")
     ap.add_argument('--kernel-breakdown', action='store_true', help='print the per-kernel launch log summary to stderr')
+    ap.add_argument('--single-thread-autograd', action='store_true',
+                    help='run backward on the calling thread (profiling under rocprofv3 counter collection: see DESIGN.md, "queue interception")')
     ap.add_argument('--launch-log', default=None, metavar='FILE', help='write the launch log of the timed region (one JSON record per launch, in launch order)')
     args = ap.parse_args()
 
@@ -215,6 +217,8 @@ def main():
         torch.distributed.init_process_group(backend, **(dict(device_id=device) if backend == 'nccl' else {}))
     assert world == args.gpus or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
 
+    if args.single_thread_autograd:
+        torch.autograd.set_multithreading_enabled(False)
     wl = workload(args.workload, args.res)
     res = wl['res']
     steps = args.steps if args.steps is not None else wl['steps']

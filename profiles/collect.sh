@@ -10,7 +10,10 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-CMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+# --single-thread-autograd: every kernel is submitted by ONE host thread.  With the default (backward on autograd's device thread) the
+# counter-collection passes died intermittently in their first seconds inside the profiler's queue interception -- once as a queue abort
+# (HSA_STATUS_ERROR_INVALID_PACKET_FORMAT, round 1), once as a SIGSEGV in a copy below hipLaunchKernel on the autograd thread (round 2).
+CMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --single-thread-autograd"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- $CMD --launch-log $OUT/launch_log.jsonl > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 echo "stats pass done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o $TAG --output-format csv -- $CMD > /dev/null 2> $OUT/fetch.log

@@ -97,7 +97,7 @@ class DiscriminatorBlock(torch.nn.Module):
             y = self.skip(x, gain=np.sqrt(0.5))
             x = self.conv0(x)
             x = self.conv1(x, gain=np.sqrt(0.5))
-            x = y.add_(x)
+            x = y + x       # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
         else:
             x = self.conv0(x)
             x = self.conv1(x)
