@@ -220,6 +220,15 @@ int sbg_sn_power_iteration(const float* W, const float* u, float* v, float* u_ne
 int sbg_attention_supported(int Q, int M, int D, int DV);
 int sbg_attention_fwd(const float* theta, const float* phi, const float* g, float* out, int N, int Q, int M, int D, int DV,
                       sbg_stream_t stream);
+/* First-order gradients of the same expression (what autograd derives from the reference's bmm / softmax / bmm, layers.py:162-166):
+ *   dg = P^T dout,  dS = P o (dout g^T - rowsum(dout o out)),  dtheta = dS phi,  dphi = dS^T theta,   P = softmax(theta phi^T)
+ * recomputed from theta / phi / g in two passes (per query tile, per key tile); the [Q, M] map never touches HBM and every sum over
+ * queries stays inside one wave (fixed order).  workspace: sbg_attention_bwd_workspace(N, Q) bytes of row statistics.
+ * Supported: the forward's shapes with D <= 64 and DV / 16 in {1, 2, 4, 8, 16} (sbg_attention_bwd_supported). */
+int sbg_attention_bwd_supported(int Q, int M, int D, int DV);
+int64_t sbg_attention_bwd_workspace(int N, int Q);
+int sbg_attention_bwd(const float* theta, const float* phi, const float* g, const float* dout, float* dtheta, float* dphi, float* dg,
+                      void* workspace, int N, int Q, int M, int D, int DV, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp32 master weights <-> packed convolution operands.  Replaces the per-call framework chain `w = self.weight * weight_gain`,

@@ -116,6 +116,9 @@ SYMBOLS = [
     ("sbg_sn_power_iteration", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int, _c.c_int, _c.c_float, _c.c_void_p]),
     ("sbg_attention_supported", _c.c_int, [_c.c_int] * 4),
     ("sbg_attention_fwd", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 5 + [_c.c_void_p]),
+    ("sbg_attention_bwd_supported", _c.c_int, [_c.c_int] * 4),
+    ("sbg_attention_bwd_workspace", _c.c_int64, [_c.c_int, _c.c_int]),
+    ("sbg_attention_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_dot_hw_splits", _c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64]),
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_modconv_bwd_supported", _c.c_int, [_c.c_int]),

@@ -171,10 +171,22 @@ class _AttentionCore(torch.autograd.Function):
                 out = _attention_reference(*ins)
                 grads = torch.autograd.grad(out, ins, dout, create_graph=True)
         else:
-            with torch.enable_grad():
-                ins = [t.detach().requires_grad_(True) for t in (theta, phi, g)]
-                out = _attention_reference(*ins)
-            grads = torch.autograd.grad(out, ins, dout)
+            lib = _lib.load()
+            n, q, d = theta.shape
+            m, dv = g.shape[1], g.shape[2]
+            if lib.sbg_attention_bwd_supported(q, m, d, dv):
+                # first order: the recompute-softmax backward kernels (two passes, no [N, Q, M] map in HBM)
+                t32, p32, g32, do32 = [t.to(torch.float32).contiguous() for t in (theta, phi, g, dout)]
+                grads = [torch.empty_like(t) for t in (t32, p32, g32)]
+                ws = torch.empty([lib.sbg_attention_bwd_workspace(n, q)], dtype=torch.uint8, device=theta.device)
+                _lib.check(lib.sbg_attention_bwd(_lib.ptr(t32), _lib.ptr(p32), _lib.ptr(g32), _lib.ptr(do32), _lib.ptr(grads[0]), _lib.ptr(grads[1]),
+                                                 _lib.ptr(grads[2]), _lib.ptr(ws), n, q, m, d, dv, _lib.stream_ptr(theta.device)), "sbg_attention_bwd")
+                grads = [gr.to(t.dtype) for gr, t in zip(grads, (theta, phi, g))]
+            else:
+                with torch.enable_grad():
+                    ins = [t.detach().requires_grad_(True) for t in (theta, phi, g)]
+                    out = _attention_reference(*ins)
+                grads = torch.autograd.grad(out, ins, dout)
         return tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad))
 
 
