@@ -24,6 +24,8 @@ _MAP = {
     "train_parts.optimizers": "train_parts.optimizers",
     "train_parts.trainers": "train_parts.trainers",
     "biggan.layers": "biggan.layers",
+    "stylegan2ada.metrics.metric_main": "metrics.metric_main",
+    "stylegan2ada.metrics.metric_utils": "metrics.metric_utils",
     "utils": "utils",
 }
 

@@ -305,6 +305,13 @@ class BaseTrainer:
                              "reference .pkl snapshots are pickled modules; neither is loaded here -- pass a .pt written by save_snapshot)")
         self.run_dir = os.path.join(str(config.log.output), str(config.exp.name)) if config.exp.get("name", utils.MISSING) != utils.MISSING else None
         self.snapshot_iterations = None     # iterations between snapshots; None = only on request
+        from ..metrics import metric_main
+        self.metrics = [str(m) for m in config.log.get("metrics", [])]      # reference :215-217
+        bad = [m for m in self.metrics if not metric_main.is_valid_metric(m)]
+        if bad:
+            raise ValueError(f"log.metrics contains {bad}; valid: {metric_main.list_valid_metrics()}")
+        self.metric_detector = config.log.get("metric_detector", None)      # local TorchScript file (or directory holding the reference's file names)
+        self.stats_metrics, self.metrics_time = dict(), 0.0
         self.config = config
         self.num_gpus, self.batch_size, self.batch_gpu = gpus, gen.batch, batch_gpu
         if self.real_data:      # reference :230-261: probe the data once, then be explicit about resolution / labels / size
@@ -457,6 +464,35 @@ class BaseTrainer:
             with open(os.path.join(run_dir, "training_options.json"), "wt") as f:
                 json.dump(options, f, indent=2)
         return path
+
+    def evaluate_metrics(self, snapshot_path=None, detector=None, metrics=None):
+        """every configured metric on G_ema (G when the average is off) against the training set (reference :659-674).  The feature
+        detector must be local (`log.metric_detector=<TorchScript file | directory>` or the `detector` argument: a path or a callable);
+        the reference's URL fetch does not exist here, so without one this raises instead of silently skipping."""
+        from ..metrics import metric_main
+        detector = detector if detector is not None else self.metric_detector
+        names = list(self.metrics if metrics is None else metrics)
+        if not names:
+            return {}
+        if not self.real_data:
+            raise ValueError("metrics need a real data set (data.dataset=image_folder ...)")
+        kw = dict(detector=None, detector_dir=None)
+        if callable(detector) or (isinstance(detector, str) and os.path.isfile(detector)):
+            kw["detector"] = detector
+        elif isinstance(detector, str) and os.path.isdir(detector):
+            kw["detector_dir"] = detector
+        else:
+            raise ValueError("no local feature detector: set log.metric_detector=<TorchScript file or directory> (detectors are not downloaded)")
+        G = self.engine.G_ema if self.engine.G_ema is not None else self.engine.G
+        self.metrics_time = 0.0
+        for metric in names:
+            result = metric_main.calc_metric(metric=metric, dataset_name=self.config.data.dataset, G=G, dataset_kwargs=self.training_set_kwargs,
+                                             num_gpus=self.num_gpus, rank=self.rank, device=self.engine.device, **kw)
+            self.metrics_time += result["total_time"]
+            if self.rank == 0:
+                metric_main.report_metric(result, run_dir=self.run_dir, snapshot_pkl=snapshot_path)
+            self.stats_metrics.update(result.results)
+        return dict(self.stats_metrics)
 
     def resume(self, path, networks_only=False):
         state = torch.load(path, map_location=self.engine.device, weights_only=True)

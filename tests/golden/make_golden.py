@@ -543,6 +543,108 @@ def gen_host_step():
                                  gen_regs=[['ppl', dict(pl_batch_shrink=2, pl_decay=0.01, pl_weight=2.)]], dis_regs=[['r1', dict(r1_gamma=1.0)]],
                                  g_reg_interval=2, d_reg_interval=2, opt=opt, batch=4, batch_gpu=4, iterations=3, ema_kimg=0.02, ema_rampup=None), "ppl")
 
+# ---------------------------------------------------------------------------------------------------------------- quality metrics
+
+def gen_metrics():
+    """the reference's metric arithmetic (stylegan2ada/metrics: FeatureStats moments, compute_fid / compute_kid / compute_is / compute_pr) on
+    synthetic feature sets: its two feature loops are replaced by functions that hand back FeatureStats filled with the fixture's features
+    (the detectors are URL fetches), everything downstream is the reference's own code on CPU."""
+    _import_train_parts()
+    from stylegan2ada.metrics import metric_utils as R_mu
+    from stylegan2ada.metrics import frechet_inception_distance as R_fid, kernel_inception_distance as R_kid
+    from stylegan2ada.metrics import inception_score as R_is, precision_recall as R_pr
+    rng = np.random.RandomState(600)
+    F = 24
+    mix = rng.randn(F, F) * 0.3 + np.eye(F)
+    real = (rng.randn(320, F) @ mix + 0.5).astype(np.float32)
+    gen = (rng.randn(256, F) @ (mix * 0.8) + rng.randn(F) * 0.3).astype(np.float32)
+    logits = rng.randn(200, 10) * 2
+    probs = (np.exp(logits) / np.exp(logits).sum(1, keepdims=True)).astype(np.float32)
+    arrays = dict(real=real, gen=gen, probs=probs)
+
+    def stats_of(x, **kw):
+        st = R_mu.FeatureStats(**kw)
+        for part in np.array_split(x, 5):       # several appends, like the feature loops
+            st.append(part)
+        return st
+
+    st = stats_of(real, capture_mean_cov=True, capture_all=True, max_items=300)     # max_items clips the last append
+    mean, cov = st.get_mean_cov()
+    arrays.update(stats_mean=mean, stats_cov=cov, stats_all=st.get_all(), stats_num=np.asarray(st.num_items))
+
+    opts = R_mu.MetricOptions(num_gpus=1, rank=0, device=torch.device('cpu'), cache=False)
+    current = {}
+
+    def fake_dataset(opts=None, max_items=None, **kw):
+        flags = {k: v for k, v in kw.items() if k in ('capture_all', 'capture_mean_cov')}
+        x = current['real']
+        return stats_of(x, max_items=min(len(x), max_items) if max_items is not None else len(x), **flags)
+
+    def fake_generator(opts=None, max_items=None, **kw):
+        flags = {k: v for k, v in kw.items() if k in ('capture_all', 'capture_mean_cov')}
+        return stats_of(current['gen'], max_items=max_items, **flags)
+
+    saved = R_mu.compute_feature_stats_for_dataset, R_mu.compute_feature_stats_for_generator
+    R_mu.compute_feature_stats_for_dataset, R_mu.compute_feature_stats_for_generator = fake_dataset, fake_generator
+    half = torch.Tensor.to
+    try:
+        current.update(real=real, gen=gen)
+        arrays['fid'] = np.asarray(R_fid.compute_fid(opts, max_real=None, num_gen=256))
+        arrays['fid_maxreal'] = np.asarray(R_fid.compute_fid(opts, max_real=200, num_gen=128))
+        np.random.seed(601)
+        arrays['kid'] = np.asarray(R_kid.compute_kid(opts, max_real=1000, num_gen=256, num_subsets=7, max_subset_size=100))
+        current['gen'] = probs
+        arrays['is_mean_std'] = np.asarray(R_is.compute_is(opts, num_gen=200, num_splits=4))
+        current.update(real=real, gen=gen)
+        # compute_pr passes a misspelt keyword (datasetname=, precision_recall.py:41), which the stand-in absorbs; it casts features to fp16,
+        # which torch.cdist does not take on the CPU: keep them in fp32 for this CPU run (the cast is a device-memory saving, not arithmetic)
+        torch.Tensor.to = lambda self, *a, **k: self if (a and a[0] is torch.float16) else half(self, *a, **k)
+        arrays['pr'] = np.asarray(R_pr.compute_pr(opts, max_real=320, num_gen=256, nhood_size=3, row_batch_size=100, col_batch_size=64))
+    finally:
+        torch.Tensor.to = half
+        R_mu.compute_feature_stats_for_dataset, R_mu.compute_feature_stats_for_generator = saved
+    save("metrics", arrays, dict(kid_seed=601, kid_subsets=7, kid_subset_size=100, is_splits=4, pr=dict(nhood_size=3, row_batch_size=100, col_batch_size=64)))
+
+# ---------------------------------------------------------------------------------------------------------------- input pipeline
+
+def gen_datasets():
+    """the reference's ImageFolderDataset (train_parts/datasets.py:160-248) and InfiniteSampler (torch_utils/misc.py:109-140) over the
+    deterministic PNG folder of tests/golden_util.make_image_folder: item order, flips, labels, pixels, sampler index streams"""
+    import tempfile
+    _import_train_parts()
+    sys.path.insert(0, os.path.dirname(HERE))
+    from golden_util import make_image_folder
+    import train_parts.datasets as R_ds
+    from stylegan2ada.torch_utils import misc as R_misc
+    arrays, cases = {}, []
+    with tempfile.TemporaryDirectory() as d:
+        root = make_image_folder(os.path.join(d, "data"))
+        zroot = make_image_folder(os.path.join(d, "dataz"), as_zip=True)
+        for idx, (src, kw) in enumerate([(root, dict(use_labels=True)), (zroot, dict(use_labels=True)), (root, dict()),
+                                         (root, dict(use_labels=True, max_size=5, random_seed=3)), (root, dict(use_labels=True, max_size=6, xflip=True, random_seed=1)),
+                                         (root, dict(xflip=True))]):
+            ds = R_ds.datasets['image_folder'](path=src, **kw)
+            imgs = np.stack([ds[i][0] for i in range(len(ds))])
+            labs = np.stack([ds[i][1] for i in range(len(ds))])
+            det = [ds.get_details(i) for i in range(len(ds))]
+            arrays.update({f"c{idx}/images": imgs, f"c{idx}/labels": labs.astype(np.float32), f"c{idx}/raw_idx": np.asarray([int(x.raw_idx) for x in det]),
+                           f"c{idx}/xflip": np.asarray([int(x.xflip) for x in det]),
+                           f"c{idx}/get_label": np.stack([ds.get_label(i) for i in range(len(ds))]).astype(np.float32)})
+            cases.append(dict(key=f"c{idx}", zip=src.endswith('.zip'), kwargs=kw, len=len(ds), image_shape=list(ds.image_shape), label_shape=list(ds.label_shape),
+                              label_dim=int(ds.label_dim), has_labels=bool(ds.has_labels), has_onehot_labels=bool(ds.has_onehot_labels), resolution=int(ds.resolution),
+                              num_channels=int(ds.num_channels), name=ds.name))
+            ds.close()
+        ds = R_ds.datasets['image_folder'](path=root)
+        samplers = []
+        # torch 2.10's Sampler.__init__ no longer takes the data source the reference passes up (misc.py:115, written for torch 1.7): accept it
+        torch.utils.data.Sampler.__init__ = lambda self, *a, **k: None
+        for j, kw in enumerate([dict(rank=0, num_replicas=1, seed=0), dict(rank=1, num_replicas=2, seed=5), dict(rank=0, num_replicas=2, seed=5),
+                                dict(rank=2, num_replicas=4, seed=1, window_size=0.2), dict(rank=0, num_replicas=1, shuffle=False)]):
+            it = iter(R_misc.InfiniteSampler(ds, **kw))
+            arrays[f"sampler{j}"] = np.asarray([int(next(it)) for _ in range(60)])
+            samplers.append(kw)
+    save("datasets", arrays, dict(cases=cases, samplers=samplers))
+
 
 # ---------------------------------------------------------------------------------------------------------------- ADA pipe
 
@@ -589,6 +691,6 @@ def gen_augment():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks", "biggan", "augment", "sg2attent", "host_step"]
+    which = sys.argv[1:] or ["upfirdn2d", "bias_act", "conv2d_resample", "modulated_conv2d", "networks", "biggan", "augment", "sg2attent", "host_step", "metrics", "datasets"]
     for name in which:
         globals()["gen_" + name]()

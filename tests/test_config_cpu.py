@@ -192,3 +192,33 @@ def test_training_on_an_image_folder(tmp_path):
     t = starter.main(argv, max_iterations=2)
     assert t.engine.batch_idx == 2 and len(t.dataset) == 40 and t.dataset.resolution == 32 and t.training_set_kwargs["xflip"] is True
     assert all(torch.isfinite(p).all() for p in t.engine.G.parameters())
+
+
+def test_image_folder_and_sampler_against_the_reference(tmp_path):
+    """tests/golden/datasets.npz: the REFERENCE's ImageFolderDataset and InfiniteSampler over the deterministic PNG folder of
+    golden_util.make_image_folder (directory and zip, labels, max_size subset with its seed, x-flip doubling) -- item order, flip flags,
+    raw indices, pixels, one-hot labels, shape accessors and the samplers' index streams must agree exactly"""
+    import numpy as np
+    from golden_util import Golden, make_image_folder
+    from style_big_gan_amd.torch_utils import misc
+    from style_big_gan_amd.train_parts.datasets import datasets
+    g = Golden("datasets")
+    root = make_image_folder(str(tmp_path / "data"))
+    zroot = make_image_folder(str(tmp_path / "dataz"), as_zip=True)
+    for case in g.meta["cases"]:
+        k = case["key"]
+        ds = datasets["image_folder"](path=zroot if case["zip"] else root, **case["kwargs"])
+        assert len(ds) == case["len"] and list(ds.image_shape) == case["image_shape"] and list(ds.label_shape) == case["label_shape"]
+        assert ds.label_dim == case["label_dim"] and ds.has_labels == case["has_labels"] and ds.has_onehot_labels == case["has_onehot_labels"]
+        assert ds.resolution == case["resolution"] and ds.num_channels == case["num_channels"] and ds.name == case["name"]
+        imgs = np.stack([ds[i][0] for i in range(len(ds))])
+        labs = np.stack([ds[i][1] for i in range(len(ds))]).astype(np.float32)
+        assert imgs.dtype == np.uint8 and np.array_equal(imgs, g.npz[f"{k}/images"]), k
+        assert np.array_equal(labs, g.npz[f"{k}/labels"]) and np.array_equal(np.stack([ds.get_label(i) for i in range(len(ds))]).astype(np.float32), g.npz[f"{k}/get_label"])
+        det = [ds.get_details(i) for i in range(len(ds))]
+        assert [int(d.raw_idx) for d in det] == g.npz[f"{k}/raw_idx"].tolist() and [int(d.xflip) for d in det] == g.npz[f"{k}/xflip"].tolist()
+        ds.close()
+    ds = datasets["image_folder"](path=root)
+    for j, kw in enumerate(g.meta["samplers"]):
+        it = iter(misc.InfiniteSampler(ds, **kw))
+        assert [int(next(it)) for _ in range(60)] == g.npz[f"sampler{j}"].tolist(), kw

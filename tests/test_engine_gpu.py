@@ -1,0 +1,104 @@
+"""StepEngine on the GPU beyond the reference-schedule fixtures (tests/test_reference_vectors_gpu.py): snapshot -> resume continuity with
+the bf16 kernels in the loop, the mixed-precision schedules of the BASELINE configs at reduced size (ffhq_sg2: path length + R1 on a resnet
+D with conv_clamp -- the in-place residual add that bench.py at 1024x1024 tripped over; sg2attent: attention in G and D; big_gan at its real
+128x128 architecture), each checked for finite, moving weights and for the expected phase structure."""
+import io
+
+import pytest
+import torch
+
+import style_big_gan_amd  # noqa: F401
+from style_big_gan_amd.train_parts import trainers
+
+pytestmark = pytest.mark.gpu
+
+
+def _sg2_kwargs(res=32, cb=1024, cm=64, d_arch="orig", map_layers=2, attn_g=(), attn_d=(), nfp=8, clamp=256):
+    gk = dict(z_dim=32, c_dim=0, w_dim=32, img_resolution=res, img_channels=3, attentions=list(attn_g), mapping_kwargs=dict(num_layers=map_layers),
+              synthesis_kwargs=dict(channel_base=cb, channel_max=cm, num_fp16_res=nfp, block_kwargs=dict(conv_clamp=clamp)))
+    dk = dict(c_dim=0, img_resolution=res, img_channels=3, attentions=list(attn_d), architecture=d_arch, channel_base=cb, channel_max=cm, num_fp16_res=nfp,
+              conv_clamp=clamp, epilogue_kwargs=dict(mbstd_group_size=4))
+    return gk, dk
+
+
+def _finite_and_moved(eng, before_g, before_d):
+    for net, before in ((eng.G, before_g), (eng.D, before_d)):
+        assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
+        assert sum(float((a - b).abs().sum()) for a, b in zip(before, net.parameters())) > 0
+
+
+def test_snapshot_resume_continuity_on_device(dev, tmp_path):
+    """state_dict -> torch.save -> weights_only load -> a fresh engine continues exactly where the first one would have: same weights, same
+    optimizer moments, same counters, and bit-identical weights after one further iteration with identical inputs and seeds"""
+    gk, dk = _sg2_kwargs()
+    kw = dict(gen_kwargs=gk, disc_kwargs=dk, loss_arch_kwargs=dict(style_mixing_prob=0), dis_regs=[("r1", dict(r1_gamma=0.1))], g_reg_interval=4,
+              d_reg_interval=2, batch=8, batch_gpu=4, ema_kimg=0.05)
+    a = trainers.StepEngine(dev, seed=1, **kw)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for _ in range(3):
+        a.train_iteration(torch.rand(8, 3, 32, 32, device=dev, generator=gen) * 2 - 1, None)
+    buf = io.BytesIO()
+    torch.save(a.state_dict(), buf)
+    buf.seek(0)
+    state = torch.load(buf, map_location=dev, weights_only=True)
+    b = trainers.StepEngine(dev, seed=99, **kw)                         # different initialisation: everything must come from the snapshot
+    b.load_state_dict(state)
+    assert b.cur_nimg == a.cur_nimg == 24 and b.batch_idx == a.batch_idx == 3
+    for ma, mb in ((a.G, b.G), (a.D, b.D), (a.G_ema, b.G_ema)):
+        for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert torch.equal(va, vb), k
+    real = torch.rand(8, 3, 32, 32, device=dev, generator=gen) * 2 - 1
+    z = torch.randn(len(a.phases) * 8, 32, device=dev, generator=gen)
+    for eng in (a, b):
+        torch.manual_seed(1234)                                         # the synthesis noise is drawn from the device generator
+        eng.train_iteration(real, None, all_gen_z=z)
+    for ma, mb in ((a.G, b.G), (a.D, b.D), (a.G_ema, b.G_ema)):
+        for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert torch.equal(va, vb), f"{k}: resumed run diverged from the original"
+    a.close(); b.close()
+
+
+def test_ffhq_sg2_schedule_bf16(dev):
+    """configs/ffhq_sg2.yaml's recipe at 64x64: 6 mapping layers, resnet D, mbstd, R1 + path length, bf16 blocks with conv_clamp"""
+    gk, dk = _sg2_kwargs(res=64, cb=2048, cm=64, d_arch="resnet", map_layers=6)
+    eng = trainers.StepEngine(dev, gen_kwargs=gk, disc_kwargs=dk, loss_arch_kwargs=dict(style_mixing_prob=0), gen_regs=[("ppl", dict(pl_batch_shrink=2, pl_decay=0.01, pl_weight=2.))],
+                              dis_regs=[("r1", dict(r1_gamma=1.))], g_reg_interval=2, d_reg_interval=2, batch=8, batch_gpu=4, ema_kimg=0.02)
+    assert [(p.name, p.interval, p.idle) for p in eng.phases] == [("Gmain", 1, False), ("Greg", 2, False), ("Dmain", 1, False), ("Dreg", 2, False)]
+    bg, bd = [p.detach().clone() for p in eng.G.parameters()], [p.detach().clone() for p in eng.D.parameters()]
+    for _ in range(2):
+        eng.train_iteration(torch.rand(8, 3, 64, 64, device=dev) * 2 - 1, None)
+    _finite_and_moved(eng, bg, bd)
+    assert float(eng.loss.gen_regs[0].pl_mean) > 0
+    eng.close()
+
+
+def test_sg2attent_schedule_bf16(dev):
+    """configs/sg2attent.yaml at its own 32x32: attention at every G resolution and at D's 32 block, bf16 blocks, R1"""
+    gk, dk = _sg2_kwargs(res=32, cb=2048, cm=128, attn_g=[32, 16, 8, 4], attn_d=[32], nfp=3)
+    eng = trainers.StepEngine(dev, gen_kwargs=gk, disc_kwargs=dk, loss_arch_kwargs=dict(style_mixing_prob=0), dis_regs=[("r1", dict(r1_gamma=0.01))],
+                              g_reg_interval=16, d_reg_interval=4, batch=8, batch_gpu=8, ema_kimg=0.02)
+    for m in list(eng.G.modules()) + list(eng.D.modules()):
+        if type(m).__name__ == "Attention":
+            torch.nn.init.constant_(m.gamma, 0.5)            # gamma starts at 0 (identity); open the branch so its gradients are exercised
+    bg, bd = [p.detach().clone() for p in eng.G.parameters()], [p.detach().clone() for p in eng.D.parameters()]
+    eng.train_iteration(torch.rand(8, 3, 32, 32, device=dev) * 2 - 1, None)
+    _finite_and_moved(eng, bg, bd)
+    att = [m for m in eng.D.modules() if type(m).__name__ == "Attention"][0]
+    assert float(att.theta.weight.grad.abs().sum()) > 0      # the last D phase of the iteration was Dreg: R1 reached the attention weights
+    eng.close()
+
+
+def test_big_gan_128_step(dev):
+    """configs/big_gan.yaml at its real architecture (128x128, ch 64, D attention at 32, 10 classes, hinge, n_dis 4), batch 8"""
+    opt = ("adam", dict(lr=2e-4, betas=[0.0, 0.999], eps=1e-8))
+    eng = trainers.StepEngine(dev, generator="big_gan", discriminator="big_gan", loss_arch="base", loss="hinge", loss_arch_kwargs=dict(),
+                              gen_kwargs=dict(c_dim=10, img_resolution=128, G_shared=False, G_attn="0", G_init="N02", n_classes=10),
+                              disc_kwargs=dict(c_dim=10, img_resolution=128, D_attn="32", D_init="N02", n_classes=10), optim_gen=opt, optim_disc=opt,
+                              gen_regs=[], dis_regs=[], g_reg_interval=0, d_reg_interval=0, n_dis=4, batch=8, batch_gpu=8, ema_kimg=0.02)
+    assert [(p.name, p.interval) for p in eng.phases] == [("Gboth", 4), ("Dboth", 1)]
+    bg, bd = [p.detach().clone() for p in eng.G.parameters()], [p.detach().clone() for p in eng.D.parameters()]
+    c = torch.nn.functional.one_hot(torch.arange(8, device=dev) % 10, 10).float()
+    for _ in range(2):
+        eng.train_iteration(torch.rand(8, 3, 128, 128, device=dev) * 2 - 1, c)
+    _finite_and_moved(eng, bg, bd)
+    eng.close()

@@ -1,0 +1,186 @@
+"""Quality-metric plumbing on the CPU.
+
+* arithmetic against the REFERENCE: tests/golden/metrics.npz holds synthetic feature sets and what the reference's own FeatureStats /
+  compute_fid / compute_kid / compute_is / compute_pr returned for them (make_golden.gen_metrics: its feature loops replaced by the
+  fixture's features, everything downstream its own code);
+* the two feature loops end to end on an image folder and a small generator with a local detector (a fixed random projection -- the
+  reference's Inception / VGG detectors are URL fetches and are not available): cache file, max_items, data-set order;
+* two ranks over gloo: round-robin items, exchanged and interleaved features = the single-process statistics, rank 0's numbers broadcast.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import style_big_gan_amd  # noqa: F401
+from golden_util import Golden
+from style_big_gan_amd.metrics import metric_main, metric_utils, scores
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_feature_stats_and_scores_match_the_reference():
+    g = Golden("metrics")
+    real, gen, probs = g.t("real").numpy(), g.t("gen").numpy(), g.t("probs").numpy()
+    st = metric_utils.FeatureStats(capture_mean_cov=True, capture_all=True, max_items=300)
+    for part in np.array_split(real, 5):
+        st.append(part)
+    mean, cov = st.get_mean_cov()
+    assert st.num_items == int(g.npz["stats_num"]) == 300 and st.is_full()
+    assert np.allclose(mean, g.npz["stats_mean"], atol=1e-6) and np.allclose(cov, g.npz["stats_cov"], atol=1e-5)
+    assert np.array_equal(st.get_all(), g.npz["stats_all"])
+    # the torch path (what the feature loops call) gives the same moments
+    st2 = metric_utils.FeatureStats(capture_mean_cov=True, max_items=300)
+    for part in np.array_split(real, 5):
+        st2.append_torch(torch.from_numpy(part))
+    assert np.allclose(st2.get_mean_cov()[1], cov, atol=1e-12)
+
+    def moments(x, n=None):
+        s = metric_utils.FeatureStats(capture_mean_cov=True, max_items=n if n is not None else len(x))
+        s.append(x)
+        return s.get_mean_cov()
+
+    fid = scores.frechet_distance(*moments(gen), *moments(real))
+    assert abs(fid - float(g.npz["fid"])) < 1e-6 * max(1.0, abs(fid))
+    fid2 = scores.frechet_distance(*moments(gen, 128), *moments(real, 200))
+    assert abs(fid2 - float(g.npz["fid_maxreal"])) < 1e-6 * max(1.0, abs(fid2))
+    np.random.seed(g.meta["kid_seed"])
+    kid = scores.kernel_distance(real, gen, g.meta["kid_subsets"], g.meta["kid_subset_size"])
+    assert abs(kid - float(g.npz["kid"])) < 1e-9 + 1e-6 * abs(kid)
+    is_mean, is_std = scores.inception_score(probs, g.meta["is_splits"])
+    assert np.allclose([is_mean, is_std], g.npz["is_mean_std"], rtol=1e-6)
+    pr = scores.precision_recall(torch.from_numpy(real), torch.from_numpy(gen), **g.meta["pr"])
+    assert np.allclose(pr, g.npz["pr"], atol=1e-7) and 0 < pr[0] < 1
+
+
+def test_feature_stats_cache_file_roundtrip(tmp_path):
+    st = metric_utils.FeatureStats(capture_mean_cov=True, capture_all=True, max_items=50)
+    st.append(np.random.RandomState(0).randn(64, 6))
+    path = str(tmp_path / "stats.npz")
+    st.save(path)
+    back = metric_utils.FeatureStats.load(path)
+    assert back.num_items == 50 and back.max_items == 50 and back.capture_all and back.capture_mean_cov
+    assert np.array_equal(back.get_all(), st.get_all()) and np.array_equal(back.get_mean_cov()[1], st.get_mean_cov()[1])
+    with np.load(path, allow_pickle=False) as z:      # plain arrays: nothing to unpickle
+        assert "raw_cov" in z.files
+
+
+def _make_image_folder(root, n, res=32):
+    import PIL.Image
+    rng = np.random.RandomState(1)
+    os.makedirs(os.path.join(root, "00000"), exist_ok=True)
+    names = []
+    for i in range(n):
+        name = f"00000/img{i:05d}.png"
+        PIL.Image.fromarray(rng.randint(0, 256, [res, res, 3], dtype=np.uint8)).save(os.path.join(root, name))
+        names.append(name)
+    json.dump({"labels": [[nm, i % 3] for i, nm in enumerate(names)]}, open(os.path.join(root, "dataset.json"), "w"))
+    return root
+
+
+class _Projection:
+    """local stand-in detector: uint8 images -> 16 features through a fixed random projection of the 4x4-pooled image"""
+    __name__ = "projection16"
+
+    def __init__(self):
+        self.w = torch.randn(48, 16, generator=torch.Generator().manual_seed(5)) / 48 ** 0.5
+
+    def __call__(self, images):
+        x = torch.nn.functional.adaptive_avg_pool2d(images.float() / 255.0, 4).flatten(1)
+        return x @ self.w.to(x.device)
+
+
+def _toy_generator():
+    from style_big_gan_amd.train_parts.generators import generators
+    torch.manual_seed(9)
+    G = generators["cnn32_dcgan"](z_dim=8, c_dim=0, img_resolution=32).eval()
+    G.c_dim = 0
+    return G
+
+
+def test_feature_loops_single_process(tmp_path):
+    path = _make_image_folder(str(tmp_path / "data"), 21)
+    det = _Projection()
+    opts = metric_utils.MetricOptions(G=_toy_generator(), dataset_kwargs=dict(path=path, use_labels=False), num_gpus=1, rank=0, device=torch.device("cpu"),
+                                      detector=det, cache=True, cache_dir=str(tmp_path / "cache"))
+    loader = dict(num_workers=0)
+    st = metric_utils.compute_feature_stats_for_dataset(opts, "unused.pt", {}, batch_size=8, data_loader_kwargs=loader, capture_all=True, capture_mean_cov=True)
+    from style_big_gan_amd.train_parts.datasets import datasets
+    ds = datasets["image_folder"](path=path)
+    direct = det(torch.stack([torch.from_numpy(ds[i][0]) for i in range(len(ds))]))
+    assert st.num_items == 21 and np.allclose(st.get_all(), direct.numpy(), atol=1e-6)            # data-set order, every item once
+    assert len(os.listdir(tmp_path / "cache")) == 1                                               # statistics cached ...
+    again = metric_utils.compute_feature_stats_for_dataset(opts, "unused.pt", {}, batch_size=8, data_loader_kwargs=loader, capture_all=True, capture_mean_cov=True)
+    assert np.array_equal(again.get_all(), st.get_all())                                          # ... and served from the cache
+    capped = metric_utils.compute_feature_stats_for_dataset(opts, "unused.pt", {}, batch_size=8, data_loader_kwargs=loader, max_items=10, capture_all=True)
+    assert capped.num_items == 10
+    gen = metric_utils.compute_feature_stats_for_generator(opts, "unused.pt", {}, batch_size=8, capture_mean_cov=True, max_items=20)
+    assert gen.num_items == 20 and gen.is_full()
+    fid = scores.compute_fid(opts, max_real=None, num_gen=24)
+    assert np.isfinite(fid) and fid > 0
+    with pytest.raises(RuntimeError):           # a URL detector is refused, never fetched
+        metric_utils.get_feature_detector("https://example.invalid/inception-2015-12-05.pt")
+
+
+def test_calc_and_report_metric(tmp_path):
+    path = _make_image_folder(str(tmp_path / "data"), 12)
+
+    @metric_main.register_metric
+    def fid_tiny(opts, dataset_name="image_folder"):
+        opts.dataset_kwargs.update(max_size=None, xflip=False)
+        return dict(fid_tiny=scores.compute_fid(opts, dataset_name=dataset_name, max_real=None, num_gen=16))
+
+    assert metric_main.is_valid_metric("fid50k_full") and "is50k" in metric_main.list_valid_metrics() and metric_main.is_valid_metric("fid_tiny")
+    res = metric_main.calc_metric("fid_tiny", G=_toy_generator(), dataset_kwargs=dict(path=path), num_gpus=1, rank=0, device=torch.device("cpu"),
+                                  detector=_Projection(), cache=False)
+    assert res.metric == "fid_tiny" and np.isfinite(res.results.fid_tiny) and res.num_gpus == 1 and res.total_time > 0
+    run_dir = tmp_path / "run"
+    run_dir.mkdir()
+    metric_main.report_metric(res, run_dir=str(run_dir), snapshot_pkl=str(run_dir / "network-snapshot-000000.pt"))
+    line = json.loads(open(run_dir / "metric-fid_tiny.jsonl").read())
+    assert line["snapshot_pkl"] == "network-snapshot-000000.pt" and line["results"]["fid_tiny"] == res.results.fid_tiny
+
+
+def _world_worker(rank, world, init_file, results, path):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import style_big_gan_amd  # noqa: F401
+    from style_big_gan_amd.metrics import metric_utils as mu, scores as sc
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        det = _Projection()
+        opts = mu.MetricOptions(G=_toy_generator(), dataset_kwargs=dict(path=path), num_gpus=world, rank=rank, device=torch.device("cpu"), detector=det, cache=False)
+        st = mu.compute_feature_stats_for_dataset(opts, "unused.pt", {}, batch_size=4, data_loader_kwargs=dict(num_workers=0), capture_all=True, capture_mean_cov=True)
+        solo = mu.MetricOptions(G=opts.G, dataset_kwargs=dict(path=path), num_gpus=1, rank=0, device=torch.device("cpu"), detector=det, cache=False)
+        ref = mu.compute_feature_stats_for_dataset(solo, "unused.pt", {}, batch_size=4, data_loader_kwargs=dict(num_workers=0), capture_all=True, capture_mean_cov=True)
+        assert st.num_items == ref.num_items == 13                  # odd count: the wrapped item of the last round is clipped away
+        assert np.allclose(st.get_all(), ref.get_all(), atol=1e-6)  # interleaved back into data-set order on EVERY rank
+        assert np.allclose(st.get_mean_cov()[1], ref.get_mean_cov()[1], atol=1e-6)
+        d = sc.pairwise_distances(torch.from_numpy(ref.get_all()), torch.from_numpy(ref.get_all()), world, rank, col_batch_size=4)
+        if rank == 0:
+            assert torch.allclose(d, torch.cdist(torch.from_numpy(ref.get_all()), torch.from_numpy(ref.get_all())), atol=1e-5)
+        results[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_feature_loop_world2_gloo(tmp_path):
+    path = _make_image_folder(str(tmp_path / "data"), 13)
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mgr = mp.Manager()
+        results = mgr.dict()
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_world_worker, args=(r, world, os.path.join(d, "rdzv"), results, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=180)
+        for p in procs:
+            assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+        assert dict(results) == {0: "ok", 1: "ok"}
