@@ -107,8 +107,12 @@ for k, v in per.items():
     n = max(v['launches'], 1)
     res[k] = dict(launches=v['launches'], fetch_bytes_per_launch=round(2 * v['fetch_kib'] * 1024 / n), write_bytes_per_launch=round(v['write_kib'] * 1024 / n),
                   hbm_bytes_per_launch=round((2 * v['fetch_kib'] + v['write_kib']) * 1024 / n))
-json.dump(dict(command='python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline', formula='(2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch', kernels=res),
-          open(os.path.join(here, f'{tag}_traffic.json'), 'w'), indent=1, sort_keys=True)
+complete = bool(res) and all(find(sub, 'counter_collection.csv') for sub in ('fetch', 'write'))
+if complete:        # a traffic file is only written when BOTH TCC passes completed (bench.py reads the newest one)
+    json.dump(dict(command='python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline', formula='(2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch', kernels=res),
+              open(os.path.join(here, f'{tag}_traffic.json'), 'w'), indent=1, sort_keys=True)
+else:
+    print('traffic: FETCH_SIZE / WRITE_SIZE passes incomplete -- no traffic file written', file=sys.stderr)
 
 # ---- SQ counters per (kernel, shape)
 f = find('sq', 'counter_collection.csv')

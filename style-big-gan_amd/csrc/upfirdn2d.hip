@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, RPW == 1 ? 3 : (RPW == 2 ? 2 : 1)) void upfird
             const int R = r * WXL + j * 8 + drow;
             const int sc = (((dchunk >> 1) ^ ((R >> 1) & 3)) << 1) | (dchunk & 1);
             const int iy = oy0 - p.pady0 + r, ix = ox0 - p.padx0 + j * 8 + drow;
-            const unsigned okm = 0u - (unsigned)(((unsigned)iy < (unsigned)p.inH) & ((unsigned)ix < (unsigned)p.inW));
+            const unsigned okm = 0u - (unsigned)(((unsigned)iy < (unsigned)p.inH) & ((unsigned)ix < (unsigned)p.inW) & (j * 8 + drow < TX + FW - 1));
             const unsigned real = (unsigned)(n * (int)p.isn + iy * (int)p.isy + ix * (int)p.isx + cb0 * 64 + sc * 8) * 2u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (fir_lds_ptr)(fsm + (r * WXL + j * 8) * 128), 16, (real & okm) | (SBG_FIR_OOB & ~okm), 0, 0, 0);
         }
@@ -407,6 +407,168 @@ __global__ __launch_bounds__(256, RPW == 1 ? 3 : (RPW == 2 ? 2 : 1)) void upfird
     }
 }
 
+// Sliding-window variant of the matrix-core FIR: a workgroup owns a strip of 32 output columns x 64 channels and WALKS DOWN it, four
+// output rows per step.  The window rows live in a 12-row ring in LDS (row r of the strip's window in slot r % 12); a step needs the seven
+// rows [4s, 4s + 7), of which only the last four are new, and those are fetched by LDS-DMA one step ahead while the matrix cores work on the
+// current rows.  The tile kernel above re-reads three of every eleven window rows (and, before the column mask, 40 of 35 columns): 1.72x the
+// input bytes; here the vertical overlap is read once per strip segment and the horizontal one is 35 / 32, and the loads of step s + 1, the
+// MFMAs of step s and the stores of step s - 1 are in flight together (two workgroups per CU: 72 KB of LDS each).
+// Order inside a step: issue the prefetch -> compute from LDS -> wait for the prefetch (the stores of the previous step, issued a whole step
+// ago, have drained by then) -> barrier (every wave is done with the rows the NEXT prefetch overwrites, and sees the new rows) -> store.
+template <class T>
+__global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs p, unsigned x_bytes, int tiles_x, int cblocks, int ysegs, int seg_rows)
+{
+    constexpr int TX = 32, FH = 4, FW = 4, SR = 4;      // SR = output rows per step (one per wave)
+    constexpr int RING = 12, WXL = 48, PPR = 5;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int cb0 = b % cblocks; b /= cblocks;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ys = b % ysegs; const int n = b / ysegs;
+    const int ox0 = tx * TX;
+    const int oy_begin = ys * seg_rows;
+    const int oy_end = (oy_begin + seg_rows < p.outH) ? oy_begin + seg_rows : p.outH;
+    const int nsteps = (oy_end - oy_begin + SR - 1) / SR;
+    if (nsteps <= 0) return;
+
+    for (int i = tid; i < RING * 64; i += 256) {        // pixels 40..47 of every ring row only ever meet zero taps: keep them finite
+        const int r = i >> 6, c = i & 63;
+        *reinterpret_cast<float4_t*>(fsm + ((r * WXL + 40) * 128) + c * 16) = float4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
+    const int drow = lane >> 3, dchunk = lane & 7;
+    // window row w (0 = the first row behind output row oy_begin) -> ring slot w % RING; rows [w0, w1) are dealt to the waves piece by piece
+    auto fetch_rows = [&](int w0, int w1) {
+        for (int piece = wave + (w0 * PPR); piece < w1 * PPR; piece += 4) {
+            const int w = piece / PPR, j = piece - w * PPR;
+            const int slot = w % RING;
+            const int R = slot * WXL + j * 8 + drow;
+            const int sc = (((dchunk >> 1) ^ ((R >> 1) & 3)) << 1) | (dchunk & 1);
+            const int iy = oy_begin - p.pady0 + w, ix = ox0 - p.padx0 + j * 8 + drow;
+            const unsigned okm = 0u - (unsigned)(((unsigned)iy < (unsigned)p.inH) & ((unsigned)ix < (unsigned)p.inW) & (j * 8 + drow < TX + FW - 1));
+            const unsigned real = (unsigned)(n * (int)p.isn + iy * (int)p.isy + ix * (int)p.isx + cb0 * 64 + sc * 8) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (fir_lds_ptr)(fsm + (slot * WXL + j * 8) * 128), 16, (real & okm) | (SBG_FIR_OOB & ~okm), 0, 0, 0);
+        }
+    };
+    fetch_rows(0, SR + FH - 1);
+
+    const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
+    short8_t bt[FH];
+#pragma unroll
+    for (int ky = 0; ky < FH; ky++) {
+        const int fy = p.flip ? ky : FH - 1 - ky;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int kpix = j < 4 ? 4 * fg + j : 16 + 4 * fg + (j - 4);
+            const int kx = kpix - fi;
+            float v = 0.f;
+            if (kx >= 0 && kx < FW) v = p.f[fy * p.fsy + (p.flip ? kx : FW - 1 - kx) * p.fsx];
+            bt[ky][j] = FirMfma<T>::bits(v);
+        }
+    }
+    // the swizzle of an LDS row depends on (R >> 1) & 3 with R = slot * 48 + pixel: 48 is a multiple of 8, so the offsets are slot-independent
+    int offA[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int Rrel = 4 * fg + fq, chunk = ((c * 16) >> 3) + (fp >> 1);
+        const int sw = (((chunk >> 1) ^ ((Rrel >> 1) & 3)) << 1) | (chunk & 1);
+        offA[c] = Rrel * 128 + sw * 16 + (fp & 1) * 8;
+    }
+    T* yb = (T*)p.y + n * p.osn + cb0 * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
+    float4_t t_scale[4], t_bias[4];
+    const float t_alpha = p.tail ? p.alpha : 1.f, t_gain = p.tail ? p.act_gain : 1.f, t_cl = (p.tail && p.clamp >= 0.f) ? p.clamp : __builtin_inff();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int ch = cb0 * 64 + c * 16 + 4 * fg;
+        t_scale[c] = float4_t{p.gain, p.gain, p.gain, p.gain};
+        t_bias[c] = float4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.tail && p.oscale) t_scale[c] *= *reinterpret_cast<const float4_t*>(p.oscale + (int64_t)n * p.C + ch);
+        if (p.tail && p.bias)   t_bias[c] = *reinterpret_cast<const float4_t*>(p.bias + ch);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; s++) {
+        if (s + 1 < nsteps) fetch_rows(SR * (s + 1) + FH - 1, SR * (s + 2) + FH - 1);       // the four new rows of the next window
+        float4_t acc[2][4];
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[sg][c] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < FH; ky++) {
+            const int slot = (SR * s + wave + ky) % RING;
+            const unsigned char* rowp = fsm + (slot * WXL) * 128;
+#pragma unroll
+            for (int sg = 0; sg < 2; sg++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const unsigned char* q = rowp + sg * 16 * 128 + offA[c];
+                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fir_lds_s4_ptr)q);
+                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fir_lds_s4_ptr)(q + 16 * 128));
+                    const short8_t fa = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[sg][c] = FirMfma<T>::run(fa, bt[ky], acc[sg][c]);
+                }
+        }
+        const int oy = oy_begin + SR * s + wave;
+        // fused tail in fp32, then pack to 16-bit pairs
+        unsigned pk[2][4][2];
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++) {
+            const int ox = ox0 + sg * 16 + fi;
+            const bool okp = oy < oy_end && ox < p.outW;
+            const float nz = (p.tail && p.noise && okp) ? p.noise[n * p.noise_sn + (int64_t)oy * p.outW + ox] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float4_t v = acc[sg][c] * t_scale[c] + (t_bias[c] + nz);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { float u = v[e]; u = (u > 0.f) ? u : u * t_alpha; v[e] = __builtin_amdgcn_fmed3f(u * t_gain, -t_cl, t_cl); }
+                pk[sg][c][0] = (unsigned)(unsigned short)FirMfma<T>::bits(v[0]) | ((unsigned)(unsigned short)FirMfma<T>::bits(v[1]) << 16);
+                pk[sg][c][1] = (unsigned)(unsigned short)FirMfma<T>::bits(v[2]) | ((unsigned)(unsigned short)FirMfma<T>::bits(v[3]) << 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the prefetch has landed (and the previous step's stores drained)
+        __syncthreads();
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++) {
+            const int ox = ox0 + sg * 16 + fi;
+            const bool ok = oy < oy_end && ox < p.outW;
+            T* dst = yb + oy * p.osy + ox * p.osx;
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                const auto r0 = __builtin_amdgcn_permlane16_swap(pk[sg][c][0], pk[sg][c + 1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(pk[sg][c][1], pk[sg][c + 1][1], false, false);
+                typedef __attribute__((ext_vector_type(4))) unsigned uint4_t;
+                const uint4_t o = {r0[0], r1[0], r0[1], r1[1]};
+                if (ok) *reinterpret_cast<uint4_t*>(dst + c * 16) = o;
+            }
+        }
+    }
+}
+
+template <class T>
+static bool launch_fir_slide(const UpfirdnArgs& a, hipStream_t stream)
+{
+    constexpr int lds = 12 * 48 * 128;
+    const int64_t x_bytes = 2 * ((int64_t)(a.N - 1) * a.isn + (int64_t)(a.inH - 1) * a.isy + (int64_t)(a.inW - 1) * a.isx + a.C);
+    if (x_bytes >= (int64_t)SBG_FIR_OOB || a.isn < 0 || a.isy < 0 || a.isx < 0) return false;
+    const int tiles_x = (a.outW + 31) / 32, cblocks = a.C / 64;
+    const int64_t strips = (int64_t)a.N * tiles_x * cblocks;
+    // vertical segments: enough workgroups for two per CU on every CU, but at least 16 output rows per segment (3 overlap rows are re-read per segment)
+    int ysegs = 1;
+    while (strips * ysegs < 1024 && a.outH / (ysegs * 2) >= 16) ysegs *= 2;
+    const int seg_rows = (((a.outH + ysegs - 1) / ysegs) + 3) & ~3;
+    ysegs = (a.outH + seg_rows - 1) / seg_rows;
+    const int64_t nblk = strips * ysegs;
+    if (nblk > INT32_MAX || nblk <= 0) return false;
+    auto kern = upfirdn2d_fir_slide_kernel<T>;
+    if (!SBG_RAISE_LDS_ONCE(kern, lds)) return false;
+    SBG_LAUNCH_OR(return false, kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, cblocks, ysegs, seg_rows);
+    return true;
+}
+
 template <class T, int RPW>
 static bool launch_fir_mfma_rpw(const UpfirdnArgs& a, hipStream_t stream)
 {
@@ -418,14 +580,15 @@ static bool launch_fir_mfma_rpw(const UpfirdnArgs& a, hipStream_t stream)
     if (nblk > INT32_MAX || nblk <= 0) return false;
     auto kern = upfirdn2d_fir_mfma_kernel<T, RPW>;
     if (!SBG_RAISE_LDS_ONCE(kern, lds)) return false;
-    SBG_LAUNCH(kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, tiles_y, cblocks);
+    SBG_LAUNCH_OR(return false, kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, tiles_y, cblocks);
     return true;
 }
 
 template <class T>
 static bool launch_fir_mfma(const UpfirdnArgs& a, hipStream_t stream)
 {
-    static const char* e = sbg_env("SBG_FIR_RPW");        // experiment switch: 1 = 4 x 32 tiles (3 workgroups per CU)
+    static const char* e = sbg_env("SBG_FIR_RPW");        // experiment switch: tile kernels (1 = 4 x 32 tiles, 2 = 8 x 32, 4 = 16 x 32) instead of the sliding window
+    if (!e && a.outH >= 16) return launch_fir_slide<T>(a, stream);
     if (e && atoi(e) == 1) return launch_fir_mfma_rpw<T, 1>(a, stream);
     if (e && atoi(e) == 4) return launch_fir_mfma_rpw<T, 4>(a, stream);
     return launch_fir_mfma_rpw<T, 2>(a, stream);

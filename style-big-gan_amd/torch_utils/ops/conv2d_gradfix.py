@@ -240,8 +240,11 @@ def _igemm(x, wp, y, taps, stride, oh, ow, y_off=(0, 0), y_step=(1, 1), oscale=N
     ws = None
     tiles = -(-(n * oh * ow) // 128) * -(-cout // 128)
     ksteps = len(taps) * -(-cin // 64)
+    # (an odd channel count -- the 513-channel data gradient of the discriminator's epilogue convolution -- splits too when the result is a plain
+    # fp32 sum: only the fused-epilogue reduction stores 8-channel vectors)
+    plain_f32 = epi is None and y.dtype == torch.float32
     if ((epi is None or not accumulate) and (y.dtype == torch.float32 or not accumulate) and y_step == (1, 1) and y_off == (0, 0) and cout > 64
-            and cout % 8 == 0 and tiles < _KSPLIT_MAX_TILES and ksteps >= 16 and y.is_contiguous(memory_format=torch.channels_last)):
+            and (cout % 8 == 0 or plain_f32) and tiles < _KSPLIT_MAX_TILES and ksteps >= 16 and y.is_contiguous(memory_format=torch.channels_last)):
         p.ksplit = max(1, min(ksteps // 4, -(-_KSPLIT_TARGET // tiles)))
         if p.ksplit > 1:
             ws = torch.empty([lib.sbg_conv2d_igemm_workspace(p) // 4], dtype=torch.float32, device=x.device)
