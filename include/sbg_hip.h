@@ -212,6 +212,13 @@ int sbg_sn_power_iteration(const float* W, const float* u, float* v, float* u_ne
                            int rows, int cols, float eps, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * fp32 operands for the bf16 matrix cores: hi / mid / lo bf16 split of x, the parts concatenated along one axis in one pass.
+ *   x: fp32 [outer, C, inner] dense;  y: bf16 [outer, nseg * C, inner];  y[o, s*C + c, i] = part_{order[s]}(x[o, c, i]),
+ *   part_0 = bf16(x), part_1 = bf16(x - part_0), part_2 = bf16(x - part_0 - part_1);  nseg <= 8, order[s] in {0, 1, 2}.
+ * (No counterpart in the reference: its fp32 layers go to cuDNN / oneDNN; here they run as six bf16 MFMA products with fp32 accumulation.) */
+int sbg_split_bf16_cat(const float* x, void* y, int64_t outer, int64_t C, int64_t inner, int nseg, const int* order, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Non-local self-attention core (biggan/layers.py `Attention.forward` :162-166): for every sample n
  *   out[n, q, :] = softmax_m( theta[n, q, :] . phi[n, m, :] ) @ g[n, m, :]
  * theta: fp32 [N, Q, D], phi: fp32 [N, M, D], g: fp32 [N, M, DV], out: fp32 [N, Q, DV], all row-major dense.

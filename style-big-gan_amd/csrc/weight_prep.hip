@@ -205,3 +205,45 @@ extern "C" int sbg_demod_coefs_bwd(const float* g, const float* dcoefs, const fl
     }
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// fp32 -> bf16 hi / mid / lo split with the parts laid side by side along one axis, in one pass.
+// fp32 tensors run through the bf16 matrix cores as sum_k conv(a_part_k, b_part_k) over the concatenated reduction axis (six products of
+// three-part splits, conv2d_gradfix.py); building the concatenated operands with framework ops took ~10 launches per operand per launch.
+//   x: [outer, C, inner] fp32 dense;  y: [outer, nseg * C, inner] bf16;  y[o, s*C + c, i] = part_{order[s]}(x[o, c, i]),
+//   part_0 = bf16(x), part_1 = bf16(x - part_0), part_2 = bf16(x - part_0 - part_1).
+namespace {
+struct SplitArgs { const float* x; unsigned short* y; int64_t total; int64_t C, inner; int nseg; int order[8]; };
+
+__global__ __launch_bounds__(256) void split_bf16_cat_kernel(SplitArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.total; idx += stride) {
+        const int64_t i = idx % a.inner, oc = idx / a.inner;
+        const int64_t c = oc % a.C, o = oc / a.C;
+        const float v = a.x[idx];
+        unsigned short part[3];
+        float r = v;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { part[k] = f32_to_bf16_bits(r); r -= bf16_bits_to_f32(part[k]); }
+        unsigned short* dst = a.y + (o * a.nseg * a.C + c) * a.inner + i;
+        for (int s = 0; s < a.nseg; s++) dst[(int64_t)s * a.C * a.inner] = part[a.order[s]];
+    }
+}
+}
+
+extern "C" int sbg_split_bf16_cat(const float* x, void* y, int64_t outer, int64_t C, int64_t inner, int nseg, const int* order, sbg_stream_t stream_)
+{
+    SBG_CHECK(x && y && order, "split_bf16_cat: null pointer");
+    SBG_CHECK(outer >= 0 && C >= 1 && inner >= 1 && nseg >= 1 && nseg <= 8, "split_bf16_cat: bad sizes");
+    SplitArgs a;
+    a.x = x; a.y = (unsigned short*)y; a.total = outer * C * inner; a.C = C; a.inner = inner; a.nseg = nseg;
+    for (int s = 0; s < 8; s++) { a.order[s] = s < nseg ? order[s] : 0; SBG_CHECK(a.order[s] >= 0 && a.order[s] <= 2, "split_bf16_cat: part index out of range"); }
+    if (a.total == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 0.0, (double)a.total * (4.0 + 2.0 * nseg), {(int)(outer > INT32_MAX ? INT32_MAX : outer), (int)C, (int)inner, 4, nseg, 0, 0});
+    SBG_LAUNCH(split_bf16_cat_kernel, dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a);
+    SBG_HIP_LAUNCH_CHECK();
+    return 0;
+}

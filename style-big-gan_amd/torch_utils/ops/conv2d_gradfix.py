@@ -16,6 +16,8 @@ import contextlib
 
 import weakref
 
+import numpy as np
+
 import torch
 
 from ... import _lib
@@ -117,6 +119,37 @@ _KSPLIT_MAX_TILES = int(_os.environ.get('SBG_KSPLIT_MAX_TILES', '128'))     # ex
 _KSPLIT_TARGET = int(_os.environ.get('SBG_KSPLIT_TARGET', '256'))
 
 CONCAT_NUMEL = 1 << 22      # fp32 operands up to this many elements: fold the split passes into ONE launch (see _fold_passes)
+
+
+_ORDER6 = ((2, 0, 1, 1, 0, 0), (0, 2, 1, 0, 1, 0))      # part indices of (a, b) in the six products of _operand_passes, smallest terms first
+_ORDER3 = ((1, 0, 0), (0, 1, 0))
+
+
+def _split_cat(t, dim, order):
+    """fp32 `t` -> bf16 tensor with `len(order)` times the size along `dim`: the hi / mid / lo parts `order[s]` of t side by side, in ONE
+    kernel (sbg_split_bf16_cat).  The result keeps t's memory order (channel-minor stays channel-minor)."""
+    import ctypes
+    perm = sorted(range(t.ndim), key=lambda d: (-t.stride(d), d))
+    tt = t.permute(perm)
+    if not tt.is_contiguous():
+        tt = tt.contiguous()
+    k = perm.index(dim)
+    outer = int(np.prod(tt.shape[:k], dtype=np.int64)) if k > 0 else 1
+    C, inner = tt.shape[k], (int(np.prod(tt.shape[k + 1:], dtype=np.int64)) if k + 1 < tt.ndim else 1)
+    out = torch.empty(list(tt.shape[:k]) + [len(order) * C] + list(tt.shape[k + 1:]), dtype=torch.bfloat16, device=t.device)
+    arr = (ctypes.c_int * len(order))(*order)
+    _lib.check(_lib.load().sbg_split_bf16_cat(_lib.ptr(tt), _lib.ptr(out), outer, C, inner, len(order), arr, _lib.stream_ptr(t.device)), "sbg_split_bf16_cat")
+    inv = [perm.index(d) for d in range(t.ndim)]
+    return out.permute(inv)
+
+
+def _mfma_operands(a, b, a_cat_dim, b_cat_dim):
+    """[(a_k, b_k)]: the matrix-core launches whose sum is the product of a and b (see _operand_passes); small fp32 operands become ONE launch
+    over concatenated hi / mid / lo parts, each operand built by one kernel"""
+    if (a.dtype == torch.float32 and b.dtype == torch.float32 and a.device.type == "cuda" and a.numel() <= CONCAT_NUMEL and a.numel() > 0 and b.numel() > 0):
+        oa, ob = _ORDER6 if fp32_mfma_passes >= 6 else _ORDER3
+        return [(_split_cat(a, a_cat_dim, oa), _split_cat(b, b_cat_dim, ob))]
+    return _fold_passes(_operand_passes(a, b), a_cat_dim, b_cat_dim)
 
 
 def _fold_passes(passes, x_cat_dim, w_cat_dim):
@@ -310,7 +343,7 @@ def _conv_forward(x, w, stride, padding, epi=None, wgain=1.0):
         wpk = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
         if xp.shape[1] != cin:
             wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
-        passes = _fold_passes(_operand_passes(xp, wpk.contiguous()), 1, 2)
+        passes = _mfma_operands(xp, wpk, 1, 2)
     multi = len(passes) > 1 or len(taps) > _lib.SBG_MAX_TAPS
     y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device, memory_format=torch.channels_last)
     assert epi is None or (not multi)
@@ -342,7 +375,7 @@ def _conv_transpose_forward(x, w, stride, padding, output_padding, wgain=1.0):
         wpk = w.permute(2, 3, 1, 0).reshape(kh * kw, cout, cin)
         if xp.shape[1] != cin:
             wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
-        passes = _fold_passes(_operand_passes(xp, wpk.contiguous()), 1, 2)
+        passes = _mfma_operands(xp, wpk, 1, 2)
     # phases: output rows oy = s*o + a use taps kh == (a + p) mod s with input row o + (a + p - kh) / s
     phases = []
     need_zero = False
@@ -392,7 +425,7 @@ def _wgrad(a, b, stride, taps):
     cap, cbp = ap.shape[1], bp.shape[1]
     out = torch.empty([len(taps), cap, cbp], dtype=torch.float32, device=a.device)
     first = True
-    for aa, bb in _fold_passes(_operand_passes(ap, bp), 0, 0):
+    for aa, bb in _mfma_operands(ap, bp, 0, 0):
         aa, bb = _cl(aa), _cl(bb)
         for g0 in range(0, len(taps), _lib.SBG_MAX_TAPS):
             grp = taps[g0:g0 + _lib.SBG_MAX_TAPS]
