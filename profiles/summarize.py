@@ -14,7 +14,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 out, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-FAMILIES = ('conv_up_fir_kernel', 'conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_ksplit_reduce', 'upfirdn2d_fir_mfma_kernel',
+FAMILIES = ('conv_thin_kernel', 'upfirdn2d_fir_slide_kernel', 'conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_ksplit_reduce', 'upfirdn2d_fir_mfma_kernel',
             'upfirdn2d_fir_fixed_kernel', 'modconv_bwd_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel', 'conv_wgrad_rows_kernel', 'conv_wgrad_halo_kernel',
             'conv_wgrad_kernel', 'wgrad_reduce_kernel', 'upfirdn2d_fir_kernel', 'upfirdn2d_kernel', 'attention_bwd', 'attention_fwd', 'mbstd', 'bias_act', 'scale_nc', 'dot_hw')
 
@@ -35,9 +35,16 @@ def log_family(rec):
     """kernel family a launch-log record was served by (dims[6] carries the launcher's code, see the SbgProfScope calls in csrc/)"""
     code = rec['dims'][6]
     if rec['kind'] == 'conv_igemm':
-        return {5: 'conv_up_fir_kernel', 3: 'conv_halo_ld_kernel', 1: 'conv_k64_kernel'}.get(code // 1000000, 'conv_gather_ld_kernel' if code >= 4000000 else None)
+        top, rem = code // 1000000, code % 1000000
+        if top == 3:
+            return 'conv_halo_ld_kernel'
+        if top == 1:
+            return 'conv_k64_kernel'
+        if top == 6 and rem < 1000:
+            return 'conv_thin_kernel'
+        return 'conv_gather_ld_kernel' if top >= 4 else None
     if rec['kind'] == 'conv_wgrad':
-        return 'conv_wgrad_halo_kernel' if code >= 2000000 else ('conv_wgrad_rows_kernel' if code >= 1000 else None)
+        return 'conv_wgrad_rows_kernel' if code >= 1000000 else None      # the generic weight-gradient kernel launches once per tap group: not joined
     return None
 
 

@@ -41,8 +41,15 @@ for q in 'bc':
     print('forward a vs', q, [float((x - y).abs().max()) for x, y in zip(outs['a'], outs[q])])
 real = torch.rand(8, 3, 32, 32, device=dev, generator=gen) * 2 - 1
 z = torch.randn(len(a.phases) * 8, 32, device=dev, generator=gen)
+def poison():
+    """fill the caching allocator's free blocks with NaN: a kernel that reads memory it (or its producer) never wrote then shows up"""
+    blocks = [torch.full([n], float('nan'), device=dev) for n in (1 << 28, 1 << 27, 1 << 26, 1 << 24, 1 << 22, 1 << 20, 1 << 18, 1 << 16) for _ in range(3)]
+    blocks += [torch.full([n], float('nan'), device=dev, dtype=torch.bfloat16) for n in (1 << 28, 1 << 26, 1 << 24, 1 << 22, 1 << 20) for _ in range(3)]
+    del blocks
 grads = {}
 for name, e in engines.items():
+    if name == 'c':
+        poison()
     torch.manual_seed(1234)
     e.train_iteration(real, None, all_gen_z=z)
     grads[name] = {k: v.grad.clone() for k, v in list(e.G.named_parameters()) + [('D.' + k, v) for k, v in e.D.named_parameters()] if v.grad is not None}
@@ -53,7 +60,16 @@ def cmp(x, y):
         if d > worst[1]:
             worst = (k, d)
     return worst
-for p, q in (('b', 'c'), ('a', 'b')):
+print('first run: a vs b  G', cmp(engines['a'].G, engines['b'].G), 'D', cmp(engines['a'].D, engines['b'].D))
+print('NaN in c after poisoned iteration:', any(bool(torch.isnan(v).any()) for v in list(engines['c'].G.state_dict().values()) + list(engines['c'].D.state_dict().values())))
+# a again, from the restored snapshot: does reloading remove the difference?
+buf.seek(0)
+a.load_state_dict(torch.load(buf, map_location=dev, weights_only=True))
+torch.manual_seed(1234)
+a.train_iteration(real, None, all_gen_z=z)
+grads['a2'] = {k: v.grad.clone() for k, v in list(a.G.named_parameters()) + [('D.' + k, v) for k, v in a.D.named_parameters()] if v.grad is not None}
+engines['a2'] = a
+for p, q in (('b', 'c'), ('a2', 'b')):
     print(p, q, 'G', cmp(engines[p].G, engines[q].G), 'D', cmp(engines[p].D, engines[q].D))
     gw = max(((k, float((grads[p][k] - grads[q][k]).abs().max() / (grads[q][k].abs().max() + 1e-30))) for k in grads[p]), key=lambda t: t[1])
     print('   last-phase grads: worst relative difference', gw)

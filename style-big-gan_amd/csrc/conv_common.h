@@ -47,3 +47,6 @@ struct ConvArgs {
 // conv_k64.hip: K-step-64 LDS-DMA kernels (gather and halo-staged).  Returns SBG_OK / an error, or -1 when the launch does not
 // fit these kernels (the caller then uses the kernels of conv_igemm.hip).
 int sbg_conv_k64_dispatch(sbgconv::ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, void* workspace, int ksplit, hipStream_t stream);
+// conv_thin.hip: few-channel convolutions (Cin, Cout <= 64, one of them <= 32) as a streaming kernel with the reduction axis packed
+// over (tap, channel).  Returns SBG_OK / an error, or -1 when the launch is not a thin one.
+int sbg_conv_thin_dispatch(sbgconv::ConvArgs& a, bool bf16, hipStream_t stream);

@@ -456,6 +456,12 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
             t0 += q->ph_ntaps[i]; ptot += a.ph_P[i];
         }
         SBG_CHECK(t0 <= q->ntaps, "conv2d_igemm: phases use %d taps, %d given", t0, q->ntaps);
+        {   // few channels: one streaming launch over all phases (conv_thin.hip)
+            a.nphase = q->nphase;
+            const int rc = sbg_conv_thin_dispatch(a, q->xdtype == SBG_BF16, s);
+            if (rc >= 0) return rc;
+            a.nphase = 1;
+        }
         const int64_t tiles = ((ptot / q->nphase + 255) / 256) * q->nphase * ((q->Cout + 127) / 128);
         if (allow_dma && q->Cout > 64 && tiles >= phase_min_tiles() && x_bytes < (int64_t)0x80000000u && w_bytes < (int64_t)0x80000000u && sbg_env("SBG_CONV_NO_PHASES") == nullptr) {
             a.nphase = q->nphase;
@@ -472,6 +478,10 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
             if (rc != SBG_OK) return rc;
         }
         return SBG_OK;
+    }
+    if (q->ksplit <= 1) {   // few channels on both sides: the streaming kernel of conv_thin.hip
+        const int rc = sbg_conv_thin_dispatch(a, q->xdtype == SBG_BF16, s);
+        if (rc >= 0) return rc;
     }
     if (allow_dma) {      // K-step-64 kernels (conv_k64.hip) take every launch whose operands fit a 2 GiB buffer descriptor
         const int rc = sbg_conv_k64_dispatch(a, q->xdtype == SBG_BF16, x_bytes, w_bytes, q->workspace, q->ksplit, s);

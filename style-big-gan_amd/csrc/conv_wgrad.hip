@@ -520,7 +520,7 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
         });
         SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                           2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
-                          {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, bca * 1000 + 64});
+                          {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, 1000000 + bca * 1000 + 64});      // 1xxxxxx = rows kernel (profiles/summarize.py joins the launch log with the kernel trace on this)
         const dim3 grid(wgrad_grid(a));
 #define SBG_ROWS_LAUNCH(MFT, SS, BB, NS) SBG_LAUNCH((conv_wgrad_rows_kernel<MFT, SS, BB, NS>), grid, dim3(512), lds, s, a, ab, bb)
         if (s_ == 1 && bca == 64)       { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 64, 3);  else SBG_ROWS_LAUNCH(f16_mfma, 1, 64, 3); }
