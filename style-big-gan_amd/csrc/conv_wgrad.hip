@@ -391,6 +391,125 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Thin weight gradient: Ca, Cb <= 32 (the 16 / 32-channel layers of the 512^2 / 1024^2 blocks, configs/ffhq_sg2.yaml).  The kernels above
+// tile 64 x 64 channels; at 16 x 16 fifteen sixteenths of their MFMAs multiply padding (62 TFLOP/s, 870 GB/s on tensors that stream in a
+// sixth of the time).  Here every WAVE works alone: a K-step is 32 pixels of one image row, staged per wave in LDS as they lie in memory
+// ([pixel][channel]: the a row segment and the RY x PCOLS patch of b behind all taps), and the MFMA operands -- eight pixels of ONE channel
+// per lane -- are gathered with 16-bit LDS reads (any stride, any tap window up to 3 rows).  Each wave writes its own fp32 slab; the
+// fixed-order slab reduction above finishes (bitwise reproducible).
+template <class MF, int TA, int TB>      // 16-channel fragments of a and b
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgradArgs p, int dymin, int dxmin, int RY, int PCOLS, int wave_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned short* la = reinterpret_cast<unsigned short*>(smem + wave * wave_lds);     // [32 pixels][Ca]
+    unsigned short* lb = la + 32 * p.Ca;                                                  // [RY][PCOLS][Cb]
+    const int slab = blockIdx.x * 4 + wave;                                               // one output slab per wave
+    const int nwaves = gridDim.x * 4;
+    const int xblocks = (p.PW + 31) >> 5;
+    const int nchunks = p.N * p.PH * xblocks;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int ca8 = p.Ca >> 3, cb8 = p.Cb >> 3;
+    float4_t acc[9][TA][TB];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int i = 0; i < TA; i++)
+#pragma unroll
+            for (int j = 0; j < TB; j++) acc[t][i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    int tdy[9], tdx[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) { tdy[t] = (t < p.ntaps ? p.tap_dy[t] : 0) - dymin; tdx[t] = (t < p.ntaps ? p.tap_dx[t] : 0) - dxmin; }
+
+    for (int c = slab; c < nchunks; c += nwaves) {
+        const int xb = c % xblocks, rowid = c / xblocks;
+        const int py = rowid % p.PH, n = rowid / p.PH;
+        const int px0 = xb << 5;
+        // ---- stage a: 32 pixels x Ca channels (pixels beyond the row end = zeros)
+        for (int piece = lane; piece < 32 * ca8; piece += 64) {
+            const int px = piece / ca8, ch = (piece - px * ca8) * 8;
+            short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (px0 + px < p.PW) v = *reinterpret_cast<const short8_t*>(p.a + (int64_t)n * p.as_n + (int64_t)py * p.as_h + (int64_t)(px0 + px) * p.as_w + ch);
+            *reinterpret_cast<short8_t*>(la + piece * 8) = v;
+        }
+        // ---- stage the b patch: rows S*py + dymin + r, columns S*px0 + dxmin + col
+        const int npieces = RY * PCOLS * cb8;
+        for (int piece = lane; piece < npieces; piece += 64) {
+            const int ch = (piece % cb8) * 8, pc = piece / cb8;
+            const int col = pc % PCOLS, r = pc / PCOLS;
+            const int by = p.stride * py + dymin + r, bx = p.stride * px0 + dxmin + col;
+            short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW)
+                v = *reinterpret_cast<const short8_t*>(p.b + (int64_t)n * p.bs_n + (int64_t)by * p.bs_h + (int64_t)bx * p.bs_w + ch);
+            *reinterpret_cast<short8_t*>(lb + piece * 8) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // this wave's LDS writes are visible to its own reads
+        __builtin_amdgcn_wave_barrier();
+        // ---- operands: lane (channel fi of fragment, k-group fg) holds pixels 8 fg + j
+        short8_t fa[TA];
+#pragma unroll
+        for (int i = 0; i < TA; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) fa[i][j] = (short)la[(8 * fg + j) * p.Ca + 16 * i + fi];
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            if (t < p.ntaps) {                           // (a predicate, not a break: the tap loop must unroll so that acc[] stays in registers)
+                const unsigned short* row = lb + (tdy[t] * PCOLS + tdx[t]) * p.Cb;
+#pragma unroll
+                for (int jb = 0; jb < TB; jb++) {
+                    short8_t fb;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) fb[j] = (short)row[(p.stride * (8 * fg + j)) * p.Cb + 16 * jb + fi];
+#pragma unroll
+                    for (int i = 0; i < TA; i++) acc[t][i][jb] = Mfma<MF>::run(fa[i], fb, acc[t][i][jb]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                 // the next chunk overwrites the buffers this wave has just read
+    }
+    // ---- this wave's slab: out[t][ca][cb], lane holds rows (ca) 16 i + 4 fg + e of column (cb) 16 jb + fi
+    float* dst = p.ws + (int64_t)slab * p.ntaps_total * p.Ca * p.Cb;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        if (t < p.ntaps) {
+#pragma unroll
+            for (int i = 0; i < TA; i++)
+#pragma unroll
+                for (int jb = 0; jb < TB; jb++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int ca = 16 * i + 4 * fg + e, cb = 16 * jb + fi;
+                        if (ca < p.Ca && cb < p.Cb) dst[((int64_t)(p.tap0 + t) * p.Ca + ca) * p.Cb + cb] = acc[t][i][jb][e];
+                    }
+        }
+    }
+}
+
+struct ThinPlan { bool ok; int dymin, dxmin, RY, PCOLS, wave_lds, nwg; };
+
+static ThinPlan thin_plan(const sbg_wgrad_params* q)
+{
+    ThinPlan t; t.ok = false;
+    static const char* off = sbg_env("SBG_WGRAD_NO_THIN");
+    if (off || q->Ca > 32 || q->Cb > 32 || q->ntaps > 9 || q->ntaps < 1 || q->stride < 1 || q->stride > 2 || q->N < 1) return t;
+    int dy0 = q->tap_dy[0], dy1 = dy0, dx0 = q->tap_dx[0], dx1 = dx0;
+    for (int i = 1; i < q->ntaps; i++) {
+        if (q->tap_dy[i] < dy0) dy0 = q->tap_dy[i]; if (q->tap_dy[i] > dy1) dy1 = q->tap_dy[i];
+        if (q->tap_dx[i] < dx0) dx0 = q->tap_dx[i]; if (q->tap_dx[i] > dx1) dx1 = q->tap_dx[i];
+    }
+    if (dy1 - dy0 > 2 || dx1 - dx0 > 2) return t;
+    t.dymin = dy0; t.dxmin = dx0; t.RY = dy1 - dy0 + 1; t.PCOLS = q->stride * 31 + (dx1 - dx0) + 1;
+    t.wave_lds = ((32 * q->Ca + t.RY * t.PCOLS * q->Cb) * 2 + 15) & ~15;
+    const int64_t nchunks = (int64_t)q->N * q->PH * ((q->PW + 31) / 32);
+    int64_t nwg = (nchunks + 15) / 16;                    // at least four chunks per wave
+    if (nwg > 2048) nwg = 2048;
+    if (nwg < 1) nwg = 1;
+    t.nwg = (int)nwg;
+    t.ok = nchunks < INT32_MAX;
+    return t;
+}
+
 static void plan_split_target(WgradArgs& a, int bca, int bcb, int target);
 static void plan_split(WgradArgs& a, int bca, int bcb)
 {
@@ -452,6 +571,8 @@ static int fill_args(const sbg_wgrad_params* q, WgradArgs& a)
     a.tap0 = 0; a.ntaps_total = q->ntaps;
     if (use_big_tile(q->ntaps)) plan_split(a, 128, 128); else plan_split(a, 64, 64);
     if (rows_kernel_ok(q, a)) plan_split_target(a, rows_bca(a), 64, 512);      // one resident workgroup per CU: two waves of workgroups, half the slab traffic
+    const ThinPlan tp = thin_plan(q);
+    if (tp.ok) { a.atiles = a.btiles = 1; a.nsplit = 4 * tp.nwg; a.chunks_per_split = 0; }      // one slab per wave (conv_wgrad_thin_kernel)
     return SBG_OK;
 }
 
@@ -493,7 +614,23 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
     }
     SBG_CHECK(a.nsplit == 1 || a.ws != nullptr, "conv2d_wgrad: workspace required (%d pixel splits)", a.nsplit);
     const bool bf = (q->dtype == SBG_BF16);
-    if (rows_kernel_ok(q, a)) {
+    const ThinPlan tp = thin_plan(q);
+    if (tp.ok) {
+        const int ta = (a.Ca + 15) / 16, tb = (a.Cb + 15) / 16;
+        const int lds = 4 * tp.wave_lds;
+        SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
+                          2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * a.nsplit,
+                          {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, 3000000 + ta * 10 + tb});
+#define SBG_THIN_LAUNCH(MFT, A_, B_) do { auto kern = conv_wgrad_thin_kernel<MFT, A_, B_>; \
+        if (lds > 64 * 1024 && !SBG_RAISE_LDS_ONCE(kern, lds)) return sbg_fail(SBG_ERR_LAUNCH, "conv2d_wgrad: cannot raise the dynamic LDS limit to %d bytes", lds); \
+        SBG_LAUNCH(kern, dim3((unsigned)tp.nwg), dim3(256), lds, s, a, tp.dymin, tp.dxmin, tp.RY, tp.PCOLS, tp.wave_lds); } while (0)
+        if (bf) { if (ta == 1 && tb == 1) SBG_THIN_LAUNCH(bf16_mfma, 1, 1); else if (ta == 2 && tb == 1) SBG_THIN_LAUNCH(bf16_mfma, 2, 1);
+                  else if (ta == 1) SBG_THIN_LAUNCH(bf16_mfma, 1, 2); else SBG_THIN_LAUNCH(bf16_mfma, 2, 2); }
+        else    { if (ta == 1 && tb == 1) SBG_THIN_LAUNCH(f16_mfma, 1, 1); else if (ta == 2 && tb == 1) SBG_THIN_LAUNCH(f16_mfma, 2, 1);
+                  else if (ta == 1) SBG_THIN_LAUNCH(f16_mfma, 1, 2); else SBG_THIN_LAUNCH(f16_mfma, 2, 2); }
+#undef SBG_THIN_LAUNCH
+        SBG_HIP_LAUNCH_CHECK();
+    } else if (rows_kernel_ok(q, a)) {
         const unsigned ab = (unsigned)(2 * ((int64_t)(q->N - 1) * q->as_n + (int64_t)(q->PH - 1) * q->as_h + (int64_t)(q->PW - 1) * q->as_w + q->Ca));
         const unsigned bb = (unsigned)(2 * ((int64_t)(q->N - 1) * q->bs_n + (int64_t)(q->BH - 1) * q->bs_h + (int64_t)(q->BW - 1) * q->bs_w + q->Cb));
         const int bca = rows_bca(a);
