@@ -212,6 +212,13 @@ int sbg_sn_power_iteration(const float* W, const float* u, float* v, float* u_ne
                            int rows, int cols, float eps, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Minibatch standard deviation (train_parts/discriminators.py:313-328): x fp32 [N, C, H, W] dense, N = G * M (sample g*M + m is in group m),
+ * C = F * c.  y fp32 [N, C + F, H, W]: y[:, :C] = x and y[g*M + m, C + f] = mean_{cc,h,w} sqrt(var_g x[g*M + m, f*c + cc, h, w] + 1e-8).
+ * sbg_mbstd_bwd: first-order dx from (x, dy).  One launch each (the reference: ~10 + ~14 tensor ops on a 1 MB tensor). */
+int sbg_mbstd_fwd(const float* x, float* y, int N, int C, int HW, int G, int F, sbg_stream_t stream);
+int sbg_mbstd_bwd(const float* x, const float* dy, float* dx, int N, int C, int HW, int G, int F, sbg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * fp32 operands for the bf16 matrix cores: hi / mid / lo bf16 split of x, the parts concatenated along one axis in one pass.
  *   x: fp32 [outer, C, inner] dense;  y: bf16 [outer, nseg * C, inner];  y[o, s*C + c, i] = part_{order[s]}(x[o, c, i]),
  *   part_0 = bf16(x), part_1 = bf16(x - part_0), part_2 = bf16(x - part_0 - part_1);  nseg <= 8, order[s] in {0, 1, 2}.

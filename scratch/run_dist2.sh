@@ -1,13 +1,19 @@
 #!/bin/bash
-# rehearse the N=2 bench flow on ONE GPU (both ranks on device 0, gloo instead of RCCL)
+# rehearse the N=2 bench flow on ONE GPU (both ranks on device 0, gloo instead of RCCL): weak, strong, and the cross-replica-BN workload
 mkdir -p gpurun_out
 export SBG_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
-cat > /tmp/b2.py <<'PY'
+run() {   # tag, bench args...
+  tag=$1; shift
+  cat > /tmp/b2.py <<PY
 import os, runpy, sys
 os.environ['LOCAL_RANK'] = '0'
-sys.argv = ['bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1']
+sys.argv = ['bench.py', '--gpus', '2'] + """$*""".split()
 runpy.run_path('bench.py', run_name='__main__')
 PY
-timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 /tmp/b2.py > gpurun_out/dist2.log 2>&1
-echo "exit $?" >> gpurun_out/dist2.log
-tail -5 gpurun_out/dist2.log
+  timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 /tmp/b2.py > gpurun_out/dist2_$tag.log 2>&1
+  echo "$tag exit $?"; grep '^{"metric"' gpurun_out/dist2_$tag.log | cut -c1-330 || tail -5 gpurun_out/dist2_$tag.log
+}
+run weak --steps 2 --warmup 1 --batch 16 --batch-gpu 8
+run strong --steps 2 --warmup 1 --batch 16 --batch-gpu 8 --scaling strong
+run biggan --steps 4 --warmup 1 --workload big_gan --batch 8 --scaling strong
+run ffhq_res64 --steps 2 --warmup 1 --workload ffhq_sg2 --res 64 --batch 8 --batch-gpu 4

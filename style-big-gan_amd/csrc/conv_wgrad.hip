@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
 // sixth of the time).  Here every WAVE works alone: a K-step is 32 pixels of one image row, staged per wave in LDS as they lie in memory
 // ([pixel][channel]: the a row segment and the RY x PCOLS patch of b behind all taps), and the MFMA operands -- eight pixels of ONE channel
 // per lane -- are gathered with 16-bit LDS reads (any stride, any tap window up to 3 rows).  Each wave writes its own fp32 slab; the
-// fixed-order slab reduction above finishes (bitwise reproducible).
+// fixed-order slab reduction above finishes (bitwise reproducible).  Measured (ffhq_sg2 shapes): 16 x 16 @1024^2 2468 -> 1995 us, 32 x 16 stride 2
+// 1264 -> 1127 us; at 32 x 32 the 64 x 64 rows kernel is faster (684 vs 2147 us: the 16-bit gathers dominate), so Ca * Cb <= 512 only.
 template <class MF, int TA, int TB>      // 16-channel fragments of a and b
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(WgradArgs p, int dymin, int dxmin, int RY, int PCOLS, int wave_lds)
 {
@@ -492,7 +493,7 @@ static ThinPlan thin_plan(const sbg_wgrad_params* q)
 {
     ThinPlan t; t.ok = false;
     static const char* off = sbg_env("SBG_WGRAD_NO_THIN");
-    if (off || q->Ca > 32 || q->Cb > 32 || q->ntaps > 9 || q->ntaps < 1 || q->stride < 1 || q->stride > 2 || q->N < 1) return t;
+    if (off || q->Ca > 32 || q->Cb > 32 || q->Ca * q->Cb > 512 || q->ntaps > 9 || q->ntaps < 1 || q->stride < 1 || q->stride > 2 || q->N < 1) return t;
     int dy0 = q->tap_dy[0], dy1 = dy0, dx0 = q->tap_dx[0], dx1 = dx0;
     for (int i = 1; i < q->ntaps; i++) {
         if (q->tap_dy[i] < dy0) dy0 = q->tap_dy[i]; if (q->tap_dy[i] > dy1) dy1 = q->tap_dy[i];

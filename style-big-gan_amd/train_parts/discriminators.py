@@ -121,15 +121,51 @@ class MinibatchStdLayer(torch.nn.Module):
         N, C, H, W = x.shape
         G = min(int(self.group_size), N) if self.group_size is not None else N
         F = self.num_channels
-        c = C // F
-        y = x.reshape(G, -1, F, c, H, W)
-        y = y - y.mean(dim=0)
-        y = y.square().mean(dim=0)
-        y = (y + 1e-8).sqrt()
-        y = y.mean(dim=[2, 3, 4])
-        y = y.reshape(-1, F, 1, 1)
-        y = y.repeat(G, 1, H, W)
-        return torch.cat([x, y], dim=1)
+        if x.device.type == 'cuda' and x.dtype == torch.float32 and x.is_contiguous() and N % G == 0 and C % F == 0:
+            return _MinibatchStd.apply(x, G, F)            # one kernel per direction (csrc/mbstd.hip)
+        return _minibatch_std_composite(x, G, F)
+
+
+def _minibatch_std_composite(x, G, F):
+    """the layer as tensor ops (reference :316-328): differentiable to any order"""
+    N, C, H, W = x.shape
+    c = C // F
+    y = x.reshape(G, -1, F, c, H, W)
+    y = y - y.mean(dim=0)
+    y = y.square().mean(dim=0)
+    y = (y + 1e-8).sqrt()
+    y = y.mean(dim=[2, 3, 4])
+    y = y.reshape(-1, F, 1, 1)
+    y = y.repeat(G, 1, H, W)
+    return torch.cat([x, y], dim=1)
+
+
+class _MinibatchStd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, G, F):
+        from .. import _lib
+        N, C, H, W = x.shape
+        y = torch.empty([N, C + F, H, W], dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().sbg_mbstd_fwd(_lib.ptr(x), _lib.ptr(y), N, C, H * W, G, F, _lib.stream_ptr(x.device)), "sbg_mbstd_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (G, F)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        G, F = ctx.cfg
+        if torch.is_grad_enabled():        # R1 differentiates this gradient again: compose it from differentiable ops on the saved input
+            with torch.enable_grad():
+                xx = x if x.requires_grad else x.detach().requires_grad_(True)
+                (dx,) = torch.autograd.grad(_minibatch_std_composite(xx, G, F), xx, dy, create_graph=True)
+            return dx, None, None
+        from .. import _lib
+        N, C, H, W = x.shape
+        dyc = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(_lib.load().sbg_mbstd_bwd(_lib.ptr(x), _lib.ptr(dyc), _lib.ptr(dx), N, C, H * W, G, F, _lib.stream_ptr(x.device)), "sbg_mbstd_bwd")
+        return dx, None, None
 
 
 class DiscriminatorEpilogue(torch.nn.Module):

@@ -622,3 +622,32 @@ def test_separable_fused_kernel_against_two_passes(dev):
                         check(gg, gr, 1e-5)
                     cases += 1
     assert cases > 150
+
+
+def test_minibatch_std_kernels(dev):
+    """csrc/mbstd.hip (forward incl. the copy of x, first-order backward) against the layer as tensor ops on the CPU in float64 (the reference's
+    composition, discriminators.py:316-328): 1e-5; second order (R1 through the layer) through the composite fallback"""
+    from style_big_gan_amd.train_parts.discriminators import MinibatchStdLayer, _minibatch_std_composite
+    torch.manual_seed(5)
+    for (n, c, hw, group, f) in [(32, 512, 4, 32, 1), (8, 64, 4, 4, 1), (12, 48, 4, 4, 3), (6, 16, 8, None, 2), (4, 8, 4, 8, 1)]:
+        x = torch.randn(n, c, hw, hw) * 2 + 0.3
+        layer = MinibatchStdLayer(group, f)
+        g_ = min(int(group), n) if group is not None else n
+        xr = x.double().requires_grad_(True)
+        yr = _minibatch_std_composite(xr, g_, f)
+        w = torch.randn_like(yr)
+        (gr,) = torch.autograd.grad((yr * w).sum(), xr)
+        xd = x.to(dev).requires_grad_(True)
+        yd = layer(xd)
+        assert yd.shape == yr.shape
+        (gd,) = torch.autograd.grad((yd * w.to(dev).float()).sum(), xd)
+        assert rel_err(yd, yr.float()) < 1e-5 and rel_err(gd, gr.float()) < 1e-5, (n, c, hw, group, f, rel_err(yd, yr.float()), rel_err(gd, gr.float()))
+    # second order
+    x = torch.randn(8, 16, 4, 4)
+    def second(t, fn):
+        (g1,) = torch.autograd.grad(fn(t).square().sum(), t, create_graph=True)
+        return torch.autograd.grad(g1.square().sum(), t)[0]
+    layer = MinibatchStdLayer(4, 1)
+    ref = second(x.double().requires_grad_(True), lambda t: _minibatch_std_composite(t, 4, 1))
+    got = second(x.to(dev).requires_grad_(True), layer)
+    assert rel_err(got, ref.float()) < 1e-4
