@@ -215,7 +215,8 @@ int sbg_sn_power_iteration(const float* W, const float* u, float* v, float* u_ne
  * Minibatch standard deviation (train_parts/discriminators.py:313-328): x fp32 [N, C, H, W] dense, N = G * M (sample g*M + m is in group m),
  * C = F * c.  y fp32 [N, C + F, H, W]: y[:, :C] = x and y[g*M + m, C + f] = mean_{cc,h,w} sqrt(var_g x[g*M + m, f*c + cc, h, w] + 1e-8).
  * sbg_mbstd_bwd: first-order dx from (x, dy).  One launch each (the reference: ~10 + ~14 tensor ops on a 1 MB tensor). */
-int sbg_mbstd_fwd(const float* x, float* y, int N, int C, int HW, int G, int F, sbg_stream_t stream);
+int64_t sbg_mbstd_workspace(int N, int C, int HW, int G, int F);      /* bytes of partial sums sbg_mbstd_fwd needs */
+int sbg_mbstd_fwd(const float* x, float* y, void* workspace, int N, int C, int HW, int G, int F, sbg_stream_t stream);
 int sbg_mbstd_bwd(const float* x, const float* dy, float* dx, int N, int C, int HW, int G, int F, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

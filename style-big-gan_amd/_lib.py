@@ -114,7 +114,8 @@ SYMBOLS = [
     ("sbg_scale_shift_nc", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_sn_workspace", _c.c_int64, [_c.c_int, _c.c_int]),
     ("sbg_sn_power_iteration", _c.c_int, [_c.c_void_p] * 6 + [_c.c_int, _c.c_int, _c.c_float, _c.c_void_p]),
-    ("sbg_mbstd_fwd", _c.c_int, [_c.c_void_p, _c.c_void_p] + [_c.c_int] * 5 + [_c.c_void_p]),
+    ("sbg_mbstd_workspace", _c.c_int64, [_c.c_int] * 5),
+    ("sbg_mbstd_fwd", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_mbstd_bwd", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_split_bf16_cat", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.POINTER(_c.c_int), _c.c_void_p]),
     ("sbg_attention_supported", _c.c_int, [_c.c_int] * 4),

@@ -146,7 +146,9 @@ class _MinibatchStd(torch.autograd.Function):
         from .. import _lib
         N, C, H, W = x.shape
         y = torch.empty([N, C + F, H, W], dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().sbg_mbstd_fwd(_lib.ptr(x), _lib.ptr(y), N, C, H * W, G, F, _lib.stream_ptr(x.device)), "sbg_mbstd_fwd")
+        lib = _lib.load()
+        ws = torch.empty([max(lib.sbg_mbstd_workspace(N, C, H * W, G, F), 4) // 4], dtype=torch.float32, device=x.device)
+        _lib.check(lib.sbg_mbstd_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(ws), N, C, H * W, G, F, _lib.stream_ptr(x.device)), "sbg_mbstd_fwd")
         ctx.save_for_backward(x)
         ctx.cfg = (G, F)
         return y

@@ -109,14 +109,16 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
         b = self.bias
         if b is not None:
             b = b.to(x.dtype)
             if self.bias_gain != 1:
                 b = b * self.bias_gain
         if self.activation == 'linear' and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())
+            # b + weight_gain * (x @ W^T): the gain rides in the GEMM's alpha (forward and both backward products) instead of a pass over W
+            # per call -- twenty affine layers per synthesis pass, each a [C, 512] multiply forward and another one backward otherwise
+            return torch.addmm(b.unsqueeze(0), x, self.weight.to(x.dtype).t(), alpha=float(self.weight_gain))
+        w = self.weight.to(x.dtype) * self.weight_gain
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
 
 

@@ -245,8 +245,9 @@ class StepEngine:
         beta = 0.5 ** (global_batch / max(ema_nimg, 1e-8))
         p_ema, p = list(self.G_ema.parameters()), list(self.G.parameters())
         torch._foreach_lerp_(p_ema, p, 1.0 - beta)      # p_ema + (p - p_ema) * (1 - beta) == p.lerp(p_ema, beta)
-        for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
-            b_ema.copy_(b)
+        b_ema, b = list(self.G_ema.buffers()), list(self.G.buffers())
+        if b_ema:
+            torch._foreach_copy_(b_ema, b)              # one multi-tensor launch instead of one copy per buffer (noise constants, filters, w_avg)
 
 
 # ----------------------------------------------------------------------------------------------------------------
