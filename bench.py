@@ -133,11 +133,11 @@ PMC_KERNELS = {'conv_igemm': ('conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'c
 
 
 def pmc_traffic(kind):
-    """HBM bytes per launch of `kind` from the newest profiles/*_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of separate
+    """HBM bytes per launch of `kind` from the newest (highest tag) profiles/*_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of separate
     rocprofv3 --pmc passes over this same bench command (profiles/collect.sh; PMC counters cannot be read from inside the
     process).  Returns (bytes_per_launch, source) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))        # tags sort by round and letter: the last one is the newest
     if not files:
         return None, None
     try:
