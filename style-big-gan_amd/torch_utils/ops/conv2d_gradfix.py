@@ -118,7 +118,12 @@ import os as _os
 _KSPLIT_MAX_TILES = int(_os.environ.get('SBG_KSPLIT_MAX_TILES', '128'))     # experiment switches for the K split of few-tile launches
 _KSPLIT_TARGET = int(_os.environ.get('SBG_KSPLIT_TARGET', '256'))
 
-CONCAT_NUMEL = 1 << 22      # fp32 operands up to this many elements: fold the split passes into ONE launch (see _fold_passes)
+# fp32 operands up to this many elements run as ONE launch over the concatenated hi / mid / lo parts (each operand built by one pass of
+# sbg_split_bf16_cat: 4 B read + 12 B written per element).  The alternative -- six launches that read-modify-write the fp32 output five times,
+# fed by parts split with framework ops -- moves ~4x the bytes on large activations (BigGAN at 128x128: [48, 64, 128, 128] tensors; half of
+# that workload's step was split / accumulate traffic) and is launch-bound on small ones; it remains only as the path for operands whose
+# concatenated copy would exceed a few GB.
+CONCAT_NUMEL = 1 << 28
 
 
 _ORDER6 = ((2, 0, 1, 1, 0, 0), (0, 2, 1, 0, 1, 0))      # part indices of (a, b) in the six products of _operand_passes, smallest terms first
