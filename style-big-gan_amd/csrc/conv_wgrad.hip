@@ -537,7 +537,9 @@ static int rows_bca(const WgradArgs& a)      // a-tile width of the rows kernel:
 {
     static const char* e = sbg_env("SBG_WGRAD_BCA");
     if (e) return atoi(e) == 64 ? 64 : 128;
-    return (a.stride == 2 && a.Ca >= 128) ? 128 : 64;     // measured: +46 % at stride 2 (65-column b patch), -7 % at stride 1
+    // measured: +46 % at stride 2 (65-column b patch); at stride 1 -7..-10 % up to 512 channels, but +60 % at 1024 x 1024 channels (BigGAN's
+    // 16 x 16 layers: 256 channel tiles re-stream the same few pixels from L2, and the wider a tile halves that traffic)
+    return ((a.stride == 2 && a.Ca >= 128) || a.Ca >= 1024) ? 128 : 64;
 }
 
 static bool rows_kernel_ok(const sbg_wgrad_params* q, const WgradArgs& a)
