@@ -343,16 +343,13 @@ class GBlock(nn.Module):
         self.bn2 = self.which_bn(out_channels)
 
     def forward(self, x, y):
-        h = self.activation(self.bn1(x, y))
-        if self.upsample:
-            h = self.upsample(h)
-            x = self.upsample(x)
-        h = self.conv1(h)
-        h = self.activation(self.bn2(h, y))
-        h = self.conv2(h)
-        if self.learnable_sc:
-            x = self.conv_sc(x)
-        return h + x
+        """residual generator block (reference :375-412): bn -> relu -> [2x nearest] -> conv -> bn -> relu -> conv, plus a 1x1 shortcut on the
+        (up-sampled) input whenever the shape changes"""
+        up = self.upsample if self.upsample else (lambda t: t)
+        h = self.conv1(up(self.activation(self.bn1(x, y))))
+        h = self.conv2(self.activation(self.bn2(h, y)))
+        sc = up(x)
+        return h + (self.conv_sc(sc) if self.learnable_sc else sc)
 
 
 class DBlock(nn.Module):
@@ -371,22 +368,16 @@ class DBlock(nn.Module):
             self.conv_sc = self.which_conv(in_channels, out_channels, kernel_size=1, padding=0)
 
     def shortcut(self, x):
-        if self.preactivation:
-            if self.learnable_sc:
-                x = self.conv_sc(x)
-            if self.downsample:
-                x = self.downsample(x)
-        else:
-            if self.downsample:
-                x = self.downsample(x)
-            if self.learnable_sc:
-                x = self.conv_sc(x)
+        """1x1 convolution and 2x average pooling of the block input; pre-activation blocks convolve first, the first block pools first (:440-451)"""
+        steps = [self.conv_sc if self.learnable_sc else None, self.downsample if self.downsample else None]
+        if not self.preactivation:
+            steps.reverse()
+        for f in steps:
+            if f is not None:
+                x = f(x)
         return x
 
     def forward(self, x):
         h = self.activation(x) if self.preactivation else x     # out-of-place ReLU (it must not touch the shortcut's input)
-        h = self.conv1(h)
-        h = self.conv2(self.activation(h))
-        if self.downsample:
-            h = self.downsample(h)
-        return h + self.shortcut(x)
+        h = self.conv2(self.activation(self.conv1(h)))
+        return (self.downsample(h) if self.downsample else h) + self.shortcut(x)

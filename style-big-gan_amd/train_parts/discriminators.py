@@ -93,18 +93,15 @@ class DiscriminatorBlock(torch.nn.Module):
             x = x + y if x is not None else y
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
 
-        if self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x)
-            x = self.conv1(x, gain=np.sqrt(0.5))
-            x = y + x       # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
-        else:
-            x = self.conv0(x)
-            x = self.conv1(x)
-
+        # conv0 -> conv1 (low-pass + stride 2); 'resnet' adds the 1x1 down-sampling shortcut, both branches scaled by sqrt(1/2)
+        residual = self.architecture == 'resnet'
+        shortcut = self.skip(x, gain=np.sqrt(0.5)) if residual else None
+        x = self.conv0(x)
+        x = self.conv1(x, gain=np.sqrt(0.5)) if residual else self.conv1(x)
+        if residual:
+            x = shortcut + x     # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
         if self.attention is not None:
             x = self.attention(x.to(torch.float32)).to(dtype)
-
         assert x.dtype == dtype
         return x, img
 
@@ -199,21 +196,20 @@ class DiscriminatorEpilogue(torch.nn.Module):
 
     def forward(self, x, img, cmap, force_fp32=False):
         misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
-        dtype, fmt = torch.float32, torch.contiguous_format     # the epilogue always runs in fp32 (reference :366-367)
-        x = x.to(dtype=dtype, memory_format=fmt)
+        x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)       # the epilogue always runs in fp32 (reference :366-367)
         if self.architecture == 'skip':
             misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
-            x = x + self.fromrgb(img.to(dtype=dtype, memory_format=fmt))
-        if self.mbstd is not None:
-            x = self.mbstd(x)
-        x = self.conv(x)
-        x = self.fc(x.flatten(1))
-        x = self.out(x)
+            x = x + self.fromrgb(img.to(dtype=torch.float32, memory_format=torch.contiguous_format))
+        # [group statistics channel] -> 3x3 conv -> dense -> logits (one per sample, or a projection onto the mapped label)
+        head = [m for m in (self.mbstd, self.conv) if m is not None]
+        for m in head:
+            x = m(x)
+        logits = self.out(self.fc(x.flatten(1)))
         if self.cmap_dim > 0:
             misc.assert_shape(cmap, [None, self.cmap_dim])
-            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
-        assert x.dtype == dtype
-        return x
+            logits = (logits * cmap).sum(dim=1, keepdim=True) * (1 / np.sqrt(self.cmap_dim))
+        assert logits.dtype == torch.float32
+        return logits
 
 
 Mappingkwargs = discriminators.make_dataclass_from_init(MappingNetwork.__init__, 'Mappingkwargs', None)

@@ -204,27 +204,30 @@ class MappingNetwork(torch.nn.Module):
             self.register_buffer('w_avg', torch.zeros([w_dim]))
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
-        x = None
+        """z [N, z_dim], c [N, c_dim] -> w [N, num_ws, w_dim] (reference :232-268): normalised latent (and embedded label) through the FC stack,
+        the running average of w tracked while training, the result repeated per synthesis layer, optionally pulled towards the average"""
+        parts = []
         if self.z_dim > 0:
             misc.assert_shape(z, [None, self.z_dim])
-            x = normalize_2nd_moment(z.to(torch.float32))
+            parts.append(normalize_2nd_moment(z.to(torch.float32)))
         if self.c_dim > 0:
             misc.assert_shape(c, [None, self.c_dim])
-            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
-            x = torch.cat([x, y], dim=1) if x is not None else y
+            parts.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
+        w = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         for idx in range(self.num_layers):
-            x = getattr(self, f'fc{idx}')(x)
-        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
-            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+            w = getattr(self, f'fc{idx}')(w)
+        track = self.w_avg_beta is not None and self.training and not skip_w_avg_update
+        if track:
+            self.w_avg.copy_(torch.lerp(w.detach().mean(dim=0), self.w_avg, self.w_avg_beta))
         if self.num_ws is not None:
-            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
-        if truncation_psi != 1:
-            assert self.w_avg_beta is not None
-            if self.num_ws is None or truncation_cutoff is None:
-                x = self.w_avg.lerp(x, truncation_psi)
-            else:
-                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
-        return x
+            w = w.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi == 1:
+            return w
+        assert self.w_avg_beta is not None
+        if self.num_ws is None or truncation_cutoff is None:
+            return torch.lerp(self.w_avg, w, truncation_psi)
+        w[:, :truncation_cutoff] = torch.lerp(self.w_avg, w[:, :truncation_cutoff], truncation_psi)
+        return w
 
 
 class SynthesisLayer(torch.nn.Module):
@@ -389,37 +392,33 @@ class SynthesisBlock(torch.nn.Module):
         if fused_modconv is None:
             fused_modconv = (not self.training) and (dtype == torch.float32 or int(x.shape[0]) == 1)
 
-        if self.in_channels == 0:
-            x = self.const.to(dtype=dtype, memory_format=fmt)
-            x = x.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        lk = dict(fused_modconv=fused_modconv, **layer_kwargs)
+        first = self.in_channels == 0
+        if first:       # the learned constant, one copy per sample
+            x = self.const.to(dtype=dtype, memory_format=fmt).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
         else:
             misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
             x = x.to(dtype=dtype, memory_format=fmt)
 
-        if self.in_channels == 0:
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-        elif self.architecture == 'resnet':
-            y = self.skip(x, gain=np.sqrt(0.5))
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=np.sqrt(0.5), **layer_kwargs)
-            x = y + x       # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
-        else:
-            x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-
+        # main path: [conv0 (up-sampling)] -> conv1; 'resnet' adds a 1x1 up-sampling shortcut, both branches scaled by sqrt(1/2)
+        residual = (not first) and self.architecture == 'resnet'
+        shortcut = self.skip(x, gain=np.sqrt(0.5)) if residual else None
+        if not first:
+            x = self.conv0(x, next(w_iter), **lk)
+        x = self.conv1(x, next(w_iter), gain=np.sqrt(0.5), **lk) if residual else self.conv1(x, next(w_iter), **lk)
+        if residual:
+            x = shortcut + x     # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
         if self.attention is not None:
             x = self.attention(x.to(torch.float32)).to(dtype)
 
+        # image branch: the running fp32 image is up-sampled, and 'skip' (or the last block of any architecture) adds this block's RGB
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
-            y = y.to(dtype=torch.float32, memory_format=torch.contiguous_format)
-            img = img.add_(y) if img is not None else y
-
-        assert x.dtype == dtype
-        assert img is None or img.dtype == torch.float32
+            rgb = self.torgb(x, next(w_iter), fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            img = rgb if img is None else img.add_(rgb)
+        assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img
 
 

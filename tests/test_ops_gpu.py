@@ -651,3 +651,31 @@ def test_minibatch_std_kernels(dev):
     ref = second(x.double().requires_grad_(True), lambda t: _minibatch_std_composite(t, 4, 1))
     got = second(x.to(dev).requires_grad_(True), layer)
     assert rel_err(got, ref.float()) < 1e-4
+
+
+def test_fused_conv_bias_act_second_order_vs_oracle(dev):
+    """the R1 pattern through the fused convolution + bias + activation op (what the discriminator's layers run in bf16): gradient of
+    |d sum(y) / dx|^2 with respect to the weight and the bias, against the oracle's composition (F.conv2d + oracle bias_act) in float64 on the
+    CPU with the same bf16-representable inputs.  lrelu with gain, with and without clamp, stride 1 and 2.  Tolerance 3e-2 of the gradient's
+    max magnitude (bf16 activations; the comparison is with the ORACLE, not with the unfused HIP path)."""
+    from style_big_gan_amd.torch_utils.ops import conv_bias_act
+    torch.manual_seed(11)
+    for stride, pad, clamp in [(1, 1, None), (1, 1, 2.0), (2, 1, None)]:
+        x = (torch.randn(2, 16, 12, 12)).to(torch.bfloat16)
+        w = (torch.randn(24, 16, 3, 3) / 12).to(torch.bfloat16)
+        b = (torch.randn(24) * 0.3).to(torch.bfloat16)
+
+        def r1_like(xx, ww, bb, fwd):
+            y = fwd(xx, ww, bb)
+            (gx,) = torch.autograd.grad(y.float().sum() if y.dtype != torch.float64 else y.sum(), xx, create_graph=True)
+            pen = gx.float().square().sum() if gx.dtype != torch.float64 else gx.square().sum()
+            return y, torch.autograd.grad(pen, [ww, bb], allow_unused=True)
+
+        xr, wr, br = [t.double().requires_grad_(True) for t in (x, w, b)]
+        yr, gr = r1_like(xr, wr, br, lambda a_, w_, b_: O.bias_act(torch.nn.functional.conv2d(a_, w_, stride=stride, padding=pad), b_, act="lrelu", gain=1.3, clamp=clamp))
+        xd, wd, bd = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+        yd, gd = r1_like(xd, wd, bd, lambda a_, w_, b_: conv_bias_act.conv2d_bias_act(a_, w_, b_, stride=stride, padding=pad, act="lrelu", gain=1.3, clamp=clamp))
+        check(yd, yr.float(), 2e-2, f"fused y (stride {stride}, clamp {clamp})")
+        check(gd[0], gr[0].float(), 3e-2, f"fused d2w (stride {stride}, clamp {clamp})")
+        if gr[1] is not None and float(gr[1].abs().max()) > 0:
+            check(gd[1] if gd[1] is not None else torch.zeros_like(bd), gr[1].float(), 3e-2, f"fused d2b (stride {stride}, clamp {clamp})")
