@@ -21,7 +21,8 @@ RESAMPLE = [1, 3, 3, 1]
 def default_cfg(**kw):
     cfg = dict(z_dim=512, c_dim=0, w_dim=512, img_resolution=256, img_channels=3, channel_base=32768, channel_max=512,
                mapping_layers=8, g_architecture='skip', d_architecture='resnet', conv_clamp=None, mbstd_group_size=4,
-               mbstd_num_channels=1, w_avg_beta=0.995, lr_multiplier=0.01)
+               mbstd_num_channels=1, w_avg_beta=0.995, lr_multiplier=0.01,
+               g_attentions=(), d_attentions=())       # block resolutions with the non-local attention hook (generators.py:443-445, discriminators.py:297-299)
     cfg.update(kw)
     return cfg
 
@@ -109,7 +110,7 @@ def synthesis_num_ws(cfg):
     return n + 1        # + toRGB of the last block
 
 
-def synthesis(sd, prefix, ws, cfg, noise_mode='const', noises=None, fused_modconv=False):
+def synthesis(sd, prefix, ws, cfg, noise_mode='const', noises=None, fused_modconv=False, sn_updates=None):
     """noises: optional dict layer-prefix -> [N, 1, R, R] tensor replacing the random draw of noise_mode='random'"""
     log2 = int(np.log2(cfg['img_resolution']))
     arch = cfg['g_architecture']
@@ -136,6 +137,9 @@ def synthesis(sd, prefix, ws, cfg, noise_mode='const', noises=None, fused_modcon
         else:
             x = synthesis_layer(sd, bp + '.conv0', x, cur[:, wi], 2, clamp, noise_mode, nz(bp + '.conv0'), fused_modconv=fused_modconv); wi += 1
             x = synthesis_layer(sd, bp + '.conv1', x, cur[:, wi], 1, clamp, noise_mode, nz(bp + '.conv1'), fused_modconv=fused_modconv); wi += 1
+        if res in cfg.get('g_attentions', ()):          # end of the block, in fp32, spectral-norm power iteration advanced once (training mode)
+            from . import biggan as OB
+            x = OB.attention(sd, bp + '.attention', x, True, sn_updates if sn_updates is not None else {})
         if img is not None:
             img = O.upsample2d(img, _f())
         if is_last or arch == 'skip':
@@ -144,9 +148,9 @@ def synthesis(sd, prefix, ws, cfg, noise_mode='const', noises=None, fused_modcon
     return img
 
 
-def generator(sd, z, c, cfg, noise_mode='const', noises=None, fused_modconv=False):
+def generator(sd, z, c, cfg, noise_mode='const', noises=None, fused_modconv=False, sn_updates=None):
     ws = mapping(sd, 'mapping', z, c, cfg, num_ws=synthesis_num_ws(cfg))
-    return synthesis(sd, 'synthesis', ws, cfg, noise_mode=noise_mode, noises=noises, fused_modconv=fused_modconv)
+    return synthesis(sd, 'synthesis', ws, cfg, noise_mode=noise_mode, noises=noises, fused_modconv=fused_modconv, sn_updates=sn_updates)
 
 
 def minibatch_std(x, group_size, num_channels=1):
@@ -160,7 +164,7 @@ def minibatch_std(x, group_size, num_channels=1):
     return torch.cat([x, y], dim=1)
 
 
-def discriminator(sd, img, c, cfg):
+def discriminator(sd, img, c, cfg, sn_updates=None):
     log2 = int(np.log2(cfg['img_resolution']))
     arch = cfg['d_architecture']
     clamp = cfg['conv_clamp']
@@ -180,6 +184,9 @@ def discriminator(sd, img, c, cfg):
         else:
             x = conv2d_layer(sd, bp + '.conv0', x, activation='lrelu', conv_clamp=clamp)
             x = conv2d_layer(sd, bp + '.conv1', x, activation='lrelu', down=2, conv_clamp=clamp)
+        if res in cfg.get('d_attentions', ()):
+            from . import biggan as OB
+            x = OB.attention(sd, bp + '.attention', x, True, sn_updates if sn_updates is not None else {})
     # epilogue
     if arch == 'skip':
         x = x + conv2d_layer(sd, 'b4.fromrgb', img, activation='lrelu')

@@ -113,3 +113,28 @@ def test_networks_golden(tag):
         assert max_rel(got, g.t("gradD/" + name)) < 1e-4 or float(g.t("gradD/" + name).abs().max()) < 1e-9, name
     for name, got in grads_r1.items():
         assert max_rel(got, g.t("gradR1/" + name)) < 2e-4 or float(g.t("gradR1/" + name).abs().max()) < 1e-9, name
+
+
+def test_sg2_attention_hybrid_oracle():
+    """oracle/networks.py with the attention hook (oracle/biggan.py attention at the end of the listed blocks) against the reference's
+    train_parts models of tests/golden/sg2attent.npz: image, logits, and the spectral-norm buffers the first forward leaves behind"""
+    from golden_util import Golden
+    from oracle import networks as ON
+    g = Golden("sg2attent")
+    gk, dk = g.meta["g_kwargs"], g.meta["d_kwargs"]
+    cfg = ON.default_cfg(z_dim=gk["z_dim"], w_dim=gk["w_dim"], c_dim=0, img_resolution=gk["img_resolution"], channel_base=gk["synthesis_kwargs"]["channel_base"],
+                         channel_max=gk["synthesis_kwargs"]["channel_max"], mapping_layers=gk["mapping_kwargs"]["num_layers"], g_architecture="skip",
+                         d_architecture=dk["architecture"], mbstd_group_size=dk["epilogue_kwargs"]["mbstd_group_size"],
+                         g_attentions=tuple(gk["attentions"]), d_attentions=tuple(dk["attentions"]))
+    gsd, dsd = g.state_dict("G"), g.state_dict("D")
+    z, c = g.t("z"), torch.zeros(g.t("z").shape[0], 0)
+    upd = {}
+    with torch.no_grad():
+        img = ON.generator(gsd, z, c, cfg, noise_mode="const", sn_updates=upd)
+        logits = ON.discriminator(dsd, g.t("img"), c, cfg)
+    assert float((img - g.t("img")).abs().max() / g.t("img").abs().max()) < 1e-5
+    assert float((logits - g.t("logits")).abs().max() / g.t("logits").abs().max()) < 1e-4
+    for key in g.keys("G_after/"):
+        name = key[len("G_after/"):]
+        if name in upd:
+            assert torch.allclose(upd[name].reshape(g.t(key).shape), g.t(key), atol=1e-5), name
