@@ -24,7 +24,8 @@ from ... import _lib
 
 enabled = False                     # kept for API parity; the HIP path is always used on a ROCm device
 weight_gradients_disabled = False   # forcefully disable computation of gradients with respect to the weights
-fp32_mfma_passes = 6                # fp32 tensors: 6 = bf16 hi/mid/lo split (~fp32 accuracy), 3 = hi/lo split (rel. error ~1e-5 per product)
+import os as _os0
+fp32_mfma_passes = int(_os0.environ.get('SBG_FP32_PASSES', '6'))     # fp32 tensors: 6 = bf16 hi/mid/lo split (~fp32 accuracy), 3 = hi/lo split (rel. error ~1e-5 per product); experiment switch
 
 
 @contextlib.contextmanager
