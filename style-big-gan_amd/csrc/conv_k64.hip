@@ -438,7 +438,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         for (int c = 0; c < nslices; c++) {
             wait_vmcnt_const<0>();                       // halo(c) has landed
             __builtin_amdgcn_s_barrier();                // 18c
-            if (c + 1 < nslices && !(dbg & 2)) {
+            if (c + 1 < nslices && !(dbg & 2) && !(dbg & 32)) {       // 32: halo loads only
                 if (++chunk == kchunks) { chunk = 0; tile += G; tc = decode(tile); }
                 issue_halo(tc, chunk, (c + 1) & 1);
             }
@@ -492,7 +492,8 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             else if (newer == 1) wait_vmcnt_const<1 * WPIECES>();
             else wait_vmcnt_const<0>();
             __builtin_amdgcn_s_barrier();                // 2s
-            if (s >= 1 && issued < S && !(dbg & 2)) { issue_next(); issued++; }     // step s + 3 -> the stage step s - 1 was read from
+            if (s >= 1 && issued < S && !(dbg & 2) && !(dbg & 16)) { issue_next(); issued++; }     // step s + 3 -> the stage step s - 1 was read from (16: weight loads only)
+            else if (s >= 1 && issued < S) issued++;
             __builtin_amdgcn_s_barrier();                // 2s + 1
         }
         __builtin_amdgcn_s_barrier();                    // 2S
