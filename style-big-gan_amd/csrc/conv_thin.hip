@@ -21,10 +21,9 @@ using namespace sbgconv;
 
 namespace {
 
-template <class MF, int TC>          // TC = 16-channel output fragments: Cout <= 16 * TC
+template <class MF, int TC, int TP>  // TC = 16-channel output fragments (Cout <= 16 * TC); TP = 16-pixel fragments per wave (a wave owns 16 * TP consecutive pixels)
 __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs p, int pitch)       // pitch = LDS row pitch of the weights, in 16-bit elements
 {
-    constexpr int TP = 4;                                   // 16-pixel fragments per wave: a wave owns 64 consecutive pixels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_dy[SBG_MAX_TAPS], s_dx[SBG_MAX_TAPS], s_slab[SBG_MAX_TAPS];
     unsigned short* lw = reinterpret_cast<unsigned short*>(smem);
@@ -35,8 +34,15 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs p, int pitch)  
     const int OH = phased ? p.ph_OH[ph] : p.OH, OW = phased ? p.ph_OW[ph] : p.OW;
     const int P = phased ? p.ph_P[ph] : p.P;
     const int64_t yoff = phased ? p.ph_yoff[ph] : 0;
-    const int pix0 = blockIdx.x * 256;
-    if (pix0 >= P) return;                                  // (uniform per workgroup, before any barrier)
+    // output tile of a workgroup: (4 * TP) rows x 16 columns of ONE image -- a 2-D tile, so that the three rows of taps a wave reads are the
+    // rows its neighbours in the workgroup read too (L1 hits; a 256 x 1 strip fetched every input row through three different workgroups)
+    constexpr int TROWS = 4 * TP;
+    const int tiles_x = (OW + 15) >> 4, tiles_y = (OH + TROWS - 1) / TROWS;
+    int b_ = blockIdx.x;
+    const int tx = b_ % tiles_x; b_ /= tiles_x;
+    const int ty = b_ % tiles_y; const int n_img = b_ / tiles_y;
+    if (n_img >= p.N) return;                               // (uniform per workgroup, before any barrier)
+    (void)P;
     const int K = ntaps * p.Cin, nsteps = (K + 31) >> 5;
 
     // (tap tables first: per-lane indexing into the kernel-argument arrays would send them through scratch memory)
@@ -59,18 +65,16 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs p, int pitch)  
 
     const int fi = lane & 15, fg = lane >> 4;
     const int cin8 = p.Cin >> 3;
-    // ---- this lane's pixels (fragment j, column fi)
+    // ---- this lane's pixels: fragment j = row ty * TROWS + wave * TP + j, column tx * 16 + fi
     int iy0[TP], ix0[TP];
-    int64_t xbase[TP];
+    const int64_t xbase = (int64_t)n_img * p.xs_n;
+    const int ox = tx * 16 + fi;
 #pragma unroll
     for (int j = 0; j < TP; j++) {
-        const int pix = pix0 + wave * 64 + 16 * j + fi;
-        const bool ok = pix < P;
-        const int pp = ok ? pix : 0;
-        const int ox = pp % OW, t = pp / OW, oy = t % OH, n = t / OH;
+        const int oy = ty * TROWS + wave * TP + j;
+        const bool ok = oy < OH && ox < OW;
         iy0[j] = ok ? oy * p.stride : -(1 << 28);           // invalid pixels fail every range test
         ix0[j] = ox * p.stride;
-        xbase[j] = (int64_t)n * p.xs_n;
     }
     float4_t acc[TC][TP];
 #pragma unroll
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs p, int pitch)  
             const int iy = iy0[j] + dy, ix = ix0[j] + dx;
             short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (kok && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW)
-                v = *reinterpret_cast<const short8_t*>(p.x + xbase[j] + (int64_t)iy * p.xs_h + (int64_t)ix * p.xs_w + c0);
+                v = *reinterpret_cast<const short8_t*>(p.x + xbase + (int64_t)iy * p.xs_h + (int64_t)ix * p.xs_w + c0);
             fb[j] = v;
         }
     };
@@ -121,9 +125,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs p, int pitch)  
     const bool vec_ok = ((p.Cout & 3) == 0) && (((p.ys_n | p.ys_h | p.ys_w | yoff) & 3) == 0) && ((((uintptr_t)p.y) & 15) == 0);
 #pragma unroll
     for (int j = 0; j < TP; j++) {
-        const int pix = pix0 + wave * 64 + 16 * j + fi;
-        if (pix >= P) continue;
-        const int ox = pix % OW, t = pix / OW, oy = t % OH, n = t / OH;
+        const int oy = ty * TROWS + wave * TP + j, n = n_img;
+        if (oy >= OH || ox >= OW) continue;
         const int64_t ybase = yoff + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w;
         const float nz = (!plain && p.noise) ? p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * OW + ox] : 0.f;
 #pragma unroll
@@ -165,13 +168,17 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs p, int pitch)  
     }
 }
 
-template <class MF, int TC>
+template <class MF, int TC, int TP>
 static int launch_thin(const ConvArgs& a, int maxP, int pitch, int lds, hipStream_t stream)
 {
-    auto kern = conv_thin_kernel<MF, TC>;
+    auto kern = conv_thin_kernel<MF, TC, TP>;
     if (lds > 64 * 1024 && !SBG_RAISE_LDS_ONCE(kern, lds))
         return sbg_fail(SBG_ERR_LAUNCH, "conv2d_igemm: cannot raise the dynamic LDS limit to %d bytes", lds);
-    const dim3 grid((unsigned)((maxP + 255) / 256), (unsigned)(a.nphase > 1 ? a.nphase : 1));
+    int maxOH = a.OH, maxOW = a.OW;
+    if (a.nphase > 1) { maxOH = maxOW = 0; for (int i = 0; i < a.nphase; i++) { if (a.ph_OH[i] > maxOH) maxOH = a.ph_OH[i]; if (a.ph_OW[i] > maxOW) maxOW = a.ph_OW[i]; } }
+    const int64_t nblk = (int64_t)a.N * ((maxOH + 4 * TP - 1) / (4 * TP)) * ((maxOW + 15) / 16);     // a phase with a smaller grid leaves its surplus workgroups idle
+    if (nblk > INT32_MAX || nblk < 1) return sbg_fail(SBG_ERR_INVALID, "conv2d_igemm: grid too large");
+    const dim3 grid((unsigned)nblk, (unsigned)(a.nphase > 1 ? a.nphase : 1));
     SBG_LAUNCH(kern, grid, dim3(256), lds, stream, a, pitch);
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
@@ -209,12 +216,16 @@ int sbg_conv_thin_dispatch(ConvArgs& a, bool bf16, hipStream_t stream)
     SbgProfScope prof(stream, SBG_K_CONV_IGEMM, 2.0 * macs * a.Cout * (double)a.Cin,
                       2.0 * a.N * a.IH * a.IW * (double)a.Cin + 2.0 * a.ntaps * a.Cout * (double)a.Cin + ys * outpix * (double)a.Cout * (a.accumulate ? 2 : 1),
                       {(int)outpix, a.Cout, a.Cin, a.ntaps, a.stride, a.OH, 6000000 + TCs * 16});
+    // one or two output fragments: eight pixel fragments per wave (the A fragment read, the tap decode and the bounds math are shared by twice
+    // the pixels; measured: see DESIGN.md); four output fragments keep four (accumulator registers)
+    static const char* tp4 = sbg_env("SBG_THIN_TP4");
+    const bool wide = TCs <= 2 && tp4 && atoi(tp4) == 0 && maxP >= (1 << 16);       // measured no better than four rows per wave: off unless SBG_THIN_TP4=0
     if (bf16) {
-        if (TCs == 1) return launch_thin<bf16_mfma, 1>(a, maxP, pitch, lds, stream);
-        if (TCs == 2) return launch_thin<bf16_mfma, 2>(a, maxP, pitch, lds, stream);
-        return launch_thin<bf16_mfma, 4>(a, maxP, pitch, lds, stream);
+        if (TCs == 1) return wide ? launch_thin<bf16_mfma, 1, 8>(a, maxP, pitch, lds, stream) : launch_thin<bf16_mfma, 1, 4>(a, maxP, pitch, lds, stream);
+        if (TCs == 2) return wide ? launch_thin<bf16_mfma, 2, 8>(a, maxP, pitch, lds, stream) : launch_thin<bf16_mfma, 2, 4>(a, maxP, pitch, lds, stream);
+        return launch_thin<bf16_mfma, 4, 4>(a, maxP, pitch, lds, stream);
     }
-    if (TCs == 1) return launch_thin<f16_mfma, 1>(a, maxP, pitch, lds, stream);
-    if (TCs == 2) return launch_thin<f16_mfma, 2>(a, maxP, pitch, lds, stream);
-    return launch_thin<f16_mfma, 4>(a, maxP, pitch, lds, stream);
+    if (TCs == 1) return wide ? launch_thin<f16_mfma, 1, 8>(a, maxP, pitch, lds, stream) : launch_thin<f16_mfma, 1, 4>(a, maxP, pitch, lds, stream);
+    if (TCs == 2) return wide ? launch_thin<f16_mfma, 2, 8>(a, maxP, pitch, lds, stream) : launch_thin<f16_mfma, 2, 4>(a, maxP, pitch, lds, stream);
+    return launch_thin<f16_mfma, 4, 4>(a, maxP, pitch, lds, stream);
 }
