@@ -225,6 +225,11 @@ int sbg_mbstd_bwd(const float* x, const float* dy, float* dx, int N, int C, int 
  *   part_0 = bf16(x), part_1 = bf16(x - part_0), part_2 = bf16(x - part_0 - part_1);  nseg <= 8, order[s] in {0, 1, 2}.
  * (No counterpart in the reference: its fp32 layers go to cuDNN / oneDNN; here they run as six bf16 MFMA products with fp32 accumulation.) */
 int sbg_split_bf16_cat(const float* x, void* y, int64_t outer, int64_t C, int64_t inner, int nseg, const int* order, sbg_stream_t stream);
+/* the same split of a strided 4-D fp32 view (extents `shape`, element strides `xstrides`), written DENSELY in the view's dimension order with
+ * dimension `cat_dim` holding the nseg parts side by side: y[.., s * shape[cat_dim] + d_cat, ..] = part order[s] of x[d].  Replaces the
+ * reference's w.permute(..).contiguous() of an fp32 conv weight ahead of the launch (torch_utils/ops/conv2d_gradfix.py:94-146 hands cuDNN
+ * the strided tensor). */
+int sbg_split_bf16_cat_nd(const float* x, const int64_t* shape, const int64_t* xstrides, int cat_dim, void* y, int nseg, const int* order, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Non-local self-attention core (biggan/layers.py `Attention.forward` :162-166): for every sample n

@@ -9,7 +9,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsbg_hip.so")
+LIB_PATH = os.environ.get("SBG_HIP_LIBRARY") or os.path.join(_HERE, "libsbg_hip.so")      # SBG_HIP_LIBRARY: another build of the same C ABI (diagnosis builds)
 
 SBG_F32, SBG_F16, SBG_BF16 = 0, 1, 2
 SBG_MAX_TAPS = 16
@@ -118,6 +118,7 @@ SYMBOLS = [
     ("sbg_mbstd_fwd", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_mbstd_bwd", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_split_bf16_cat", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.POINTER(_c.c_int), _c.c_void_p]),
+    ("sbg_split_bf16_cat_nd", _c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.c_int, _c.c_void_p, _c.c_int, _c.POINTER(_c.c_int), _c.c_void_p]),
     ("sbg_attention_supported", _c.c_int, [_c.c_int] * 4),
     ("sbg_attention_fwd", _c.c_int, [_c.c_void_p] * 4 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_attention_bwd_supported", _c.c_int, [_c.c_int] * 4),

@@ -18,6 +18,7 @@
 // partial slabs; a second kernel sums the slabs in a fixed order (bitwise reproducible, no float atomics).
 #include "sbg_common.h"
 #include <cstdlib>
+#include <utility>
 
 namespace {
 
@@ -72,6 +73,23 @@ static __device__ __forceinline__ short4_t lds_tr_read(const unsigned char* p)
 {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p));
 }
+
+// the same read as inline assembly (the compiler neither schedules it nor counts it: pair with lds_wait), and the wait that hands the
+// registers back to the compiler: "+v" makes every later use of the fragment depend on the s_waitcnt
+template <int OFF>
+static __device__ __forceinline__ void lds_tr_issue(short4_t& d, unsigned addr)
+{
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+static __device__ __forceinline__ void lds_wait(short4_t& a, short4_t& b)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <class F, int... Is>
+static __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+static __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 template <class MF, int BCA, int BCB, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
@@ -237,6 +255,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
     // b patch of a 32-pixel chunk is 65 columns wide.
     // S = stride between the coarse (a) and fine (b) grids: b pixel = S * a pixel + tap, taps = (dy0 + i, dx0 + j), i, j in 0..2
     static_assert(BCA == 64 || BCA == 128, "a tile of 64 or 128 channels");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 6, "2..6 stages (the wait ladder covers five chunks in flight)");
+#ifdef SBG_WGRAD_ABL_CT     // timing-only ablation builds (scratch/wgrad_abl.py): 1 = no MFMA, 2 = no DMA inside the loop, 4 = no fragment reads
+    constexpr int ABL = SBG_WGRAD_ABL_CT;
+#else
+    constexpr int ABL = 0;
+#endif
     constexpr int BCB = 64, NT = 9, DEPTH = NSTAGE - 1;     // NSTAGE = 2 (one chunk of loads in flight) lets two workgroups share a CU where three stages would not fit twice
     constexpr int TA = BCA / 32;                               // 16-channel a fragments per wave
     constexpr int APIECES = BCA / 16;                          // a-tile = BCA / 64 sub-tiles of [32 pixels][64 channels], 4 pieces each
@@ -246,7 +270,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
     constexpr int NWAVE = 8;
     constexpr int NPIECE = ((APIECES + 3 * PPR + NWAVE - 1) / NWAVE) * NWAVE;   // a-tile + patch pieces, padded with spares
     constexpr int PIECES = NPIECE / NWAVE;                     // DMA instructions per wave per stage
-    constexpr int A_BYTES = APIECES * 1024, STAGE = NPIECE * 1024;
+    constexpr int NREAL = APIECES + 3 * PPR;                   // pieces that carry data; the spares (equal DMA counts on every wave) all land in one dump KiB behind the stages
+    constexpr int A_BYTES = APIECES * 1024, STAGE = NREAL * 1024, DUMP = NSTAGE * STAGE;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -291,13 +316,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
                 const int ch = cb0 + src_chunk(R) * 8;
                 const unsigned okm = 0u - (unsigned)((q < 3 * PPR) & ((unsigned)by < (unsigned)p.BH) & ((unsigned)bx < (unsigned)p.BW) & (ch < p.Cb));
                 const unsigned real = (unsigned)(n * (int)p.bs_n + by * (int)p.bs_h + bx * (int)p.bs_w + ch) * 2u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_void_ptr)(st + A_BYTES + q * 1024), 16, (real & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
+                unsigned char* dst = (q < 3 * PPR) ? st + A_BYTES + q * 1024 : smem + DUMP;      // (wave-uniform)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_void_ptr)dst, 16, (real & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
             }
         }
     };
 
     const int wa = (wave >> 2) * (BCA / 2), wb = (wave & 3) * 16;
     const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_void_ptr)smem);
     float4_t acc[NT][TA];
 #pragma unroll
     for (int t = 0; t < NT; t++)
@@ -328,23 +355,61 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
 #pragma unroll
     for (int s = 0; s < DEPTH; s++) if (s < nloc) issue(s);
     for (int s = 0; s < nloc; s++) {
-        if (DEPTH >= 2 && nloc - 1 - s >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
-        else                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {   // chunk s has landed once at most the loads of the (up to DEPTH - 1) chunks issued after it are outstanding
+            const int later = nloc - 1 - s;
+            if (DEPTH >= 2 && later >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH - 1) * PIECES) : "memory");
+            else if (DEPTH >= 3 && later == DEPTH - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH >= 3 ? DEPTH - 2 : 0) * PIECES) : "memory");
+            else if (DEPTH >= 4 && later == DEPTH - 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH >= 4 ? DEPTH - 3 : 0) * PIECES) : "memory");
+            else if (DEPTH >= 5 && later == DEPTH - 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH >= 5 ? DEPTH - 4 : 0) * PIECES) : "memory");
+            else                                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (s + DEPTH < nloc) issue(s + DEPTH);
-        const unsigned char* sA = smem + (s % NSTAGE) * STAGE;
-        const unsigned char* sP = sA + A_BYTES;
-        short8_t fa[TA];
+        if (!(ABL & 2))
+            if (s + DEPTH < nloc) issue(s + DEPTH);
+        // The transposing reads are issued as inline assembly with hand-counted lgkmcnt waits.  Written with the builtin, the compiler sees LDS
+        // reads behind LDS-DMA writes it cannot tell apart and guards the first read of every chunk with s_waitcnt vmcnt(0) -- the wave then
+        // waits for the loads it has just issued for chunk s + DEPTH, and the whole L2 -> LDS stream is exposed (ablation: 806 us, 532 us
+        // without the loads, 325 us MFMA only).  The explicit vmcnt(PIECES) + barrier above is the real dependence.
+        const unsigned stage = lds_base + (unsigned)((s % NSTAGE) * STAGE);
+        short4_t alo[TA], ahi[TA], blo[3], bhi[3];
+        if constexpr ((ABL & 4) != 0) {
 #pragma unroll
-        for (int i = 0; i < TA; i++) fa[i] = read_frag(sA, offA[i], 16 * 128);
+            for (int i = 0; i < TA; i++) alo[i] = ahi[i] = short4_t{(short)s, 1, 2, 3};
 #pragma unroll
-        for (int dyi = 0; dyi < 3; dyi++)
-#pragma unroll
-            for (int dxi = 0; dxi < 3; dxi++) {
-                const short8_t fb = read_frag(sP + dyi * PROW * 128, offB[dxi], S * 16 * 128);
-#pragma unroll
-                for (int i = 0; i < TA; i++) acc[dyi * 3 + dxi][i] = Mfma<MF>::run(fa[i], fb, acc[dyi * 3 + dxi][i]);
+            for (int i = 0; i < 3; i++) blo[i] = bhi[i] = short4_t{(short)s, 3, 2, 1};
+        }
+        static_for<TA>([&](auto it) {
+            constexpr int i = decltype(it)::value;
+            if constexpr ((ABL & 4) == 0) {
+                lds_tr_issue<0>(alo[i], stage + (unsigned)offA[i]);
+                lds_tr_issue<16 * 128>(ahi[i], stage + (unsigned)offA[i]);
             }
+        });
+        unsigned pb[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) pb[d] = stage + (unsigned)offB[d];
+        auto issue_b = [&](auto tt) {
+            constexpr int t = decltype(tt)::value, dyi = t / 3, dxi = t % 3, OFF = A_BYTES + dyi * PROW * 128;
+            if constexpr ((ABL & 4) == 0) {
+                lds_tr_issue<OFF>(blo[t % 3], pb[dxi]);
+                lds_tr_issue<OFF + S * 16 * 128>(bhi[t % 3], pb[dxi]);
+            }
+        };
+        issue_b(std::integral_constant<int, 0>{});
+        issue_b(std::integral_constant<int, 1>{});
+        static_for<9>([&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            if constexpr (t + 2 < 9) issue_b(std::integral_constant<int, t + 2>{});
+            if constexpr ((ABL & 4) == 0)
+                lds_wait<(t + 2 < 9 ? 4 : t + 1 < 9 ? 2 : 0)>(blo[t % 3], bhi[t % 3]);      // the reads of taps t + 1 and t + 2 may still be in flight
+            // (the a reads precede tap 0's and LDS returns in order: they have landed)
+            const short8_t fb = short8_t{blo[t % 3][0], blo[t % 3][1], blo[t % 3][2], blo[t % 3][3], bhi[t % 3][0], bhi[t % 3][1], bhi[t % 3][2], bhi[t % 3][3]};
+#pragma unroll
+            for (int i = 0; i < TA; i++) {
+                const short8_t fa_i = short8_t{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]};
+                if constexpr ((ABL & 1) == 0) acc[t][i] = Mfma<MF>::run(fa_i, fb, acc[t][i]);
+            }
+        });
     }
 
     const bool direct = (p.nsplit == 1);
@@ -537,9 +602,15 @@ static int rows_bca(const WgradArgs& a)      // a-tile width of the rows kernel:
 {
     static const char* e = sbg_env("SBG_WGRAD_BCA");
     if (e) return atoi(e) == 64 ? 64 : 128;
-    // measured: +46 % at stride 2 (65-column b patch); at stride 1 -7..-10 % up to 512 channels, but +60 % at 1024 x 1024 channels (BigGAN's
-    // 16 x 16 layers: 256 channel tiles re-stream the same few pixels from L2, and the wider a tile halves that traffic)
-    return ((a.stride == 2 && a.Ca >= 128) || a.Ca >= 1024) ? 128 : 64;
+    // 128 wherever there are 128 a channels: half the staged bytes and 0.72 instead of 1.22 fragment reads per MFMA.  (While the compiler still
+    // guarded the fragment reads with vmcnt(0), the wide tile lost 7-10 % at stride 1 up to 512 channels: one workgroup per CU, nothing overlapped.)
+    return a.Ca >= 128 ? 128 : 64;
+}
+
+static int rows_nstage(int stride, int bca)   // stages of the rows kernel (LDS: stages x (a + patch pieces) + 1 KiB).  Measured flat from 2 to 6 stages at one
+{                                             // workgroup per CU (the L2 -> LDS stream is not latency bound); what matters is that two workgroups still fit where registers allow two
+    if (bca == 128) return 4;                 // 4 x 23 + 1 = 93 KB (stride 1) / 4 x 35 + 1 = 141 KB (stride 2): one workgroup per CU (195 VGPRs)
+    return stride == 1 ? 4 : 2;               // 4 x 19 + 1 = 77 KB / 2 x 31 + 1 = 63 KB: two per CU
 }
 
 static bool rows_kernel_ok(const sbg_wgrad_params* q, const WgradArgs& a)
@@ -638,36 +709,28 @@ extern "C" int sbg_conv2d_wgrad(const sbg_wgrad_params* q, sbg_stream_t stream)
         const unsigned bb = (unsigned)(2 * ((int64_t)(q->N - 1) * q->bs_n + (int64_t)(q->BH - 1) * q->bs_h + (int64_t)(q->BW - 1) * q->bs_w + q->Cb));
         const int bca = rows_bca(a);
         const int s_ = q->stride;
-        // stage = (a pieces + 3 x patch pieces, rounded up to 8) KiB
-        auto stage_kib = [](int S, int BCA) { const int ppr = (S * 31 + 3 + 7) / 8; return ((BCA / 16 + 3 * ppr + 7) / 8) * 8; };
-        // stride 2 with the 128-channel a tile: 40 KB stages -- two of them (80 KB) admit two workgroups per CU, three do not
+        // stage = a pieces + 3 x patch pieces, 1 KiB each; one more KiB behind the stages takes the spare pieces
+        auto stage_kib = [](int S, int BCA) { const int ppr = (S * 31 + 3 + 7) / 8; return BCA / 16 + 3 * ppr; };
+        // Depth of the L2 -> LDS pipeline.  The stream is latency bound (ablation: the loads alone take 350 us on the 128-channel 256^2 layer whatever
+        // the tile, with 46 or 76 KB in flight per CU: ~1.3 us per round trip), so the kernel wants as many chunks in flight as LDS holds.
         static const char* ens = sbg_env("SBG_WGRAD_NSTAGE");
-        const int nst = (s_ == 2 && bca == 128 && !(ens && atoi(ens) == 3)) ? 2 : 3;
-        const int lds = nst * stage_kib(s_, bca) * 1024;
-        static std::once_flag rows_lds_once;
-        std::call_once(rows_lds_once, [&] {
-            const int big = 3 * stage_kib(2, 128) * 1024;
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 2, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 2, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<bf16_mfma, 1, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_kernel<f16_mfma, 1, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        });
+        int nst = rows_nstage(s_, bca);
+        if (ens && atoi(ens) >= 2 && atoi(ens) <= 6 && (atoi(ens) * stage_kib(s_, bca) + 1) <= 160) nst = atoi(ens);
+        const int lds = (nst * stage_kib(s_, bca) + 1) * 1024;
         SbgProfScope prof(s, SBG_K_CONV_WGRAD, 2.0 * (double)a.P * a.Ca * (double)a.Cb * a.ntaps,
                           2.0 * (double)a.P * a.Ca + 2.0 * (double)a.N * a.BH * a.BW * a.Cb + 4.0 * a.ntaps * (double)a.Ca * a.Cb * (a.nsplit > 1 ? a.nsplit : 1),
                           {(int)(a.P > INT32_MAX ? INT32_MAX : a.P), a.Ca, a.Cb, a.ntaps, a.stride, a.nsplit, 1000000 + bca * 1000 + 64});      // 1xxxxxx = rows kernel (profiles/summarize.py joins the launch log with the kernel trace on this)
         const dim3 grid(wgrad_grid(a));
-#define SBG_ROWS_LAUNCH(MFT, SS, BB, NS) SBG_LAUNCH((conv_wgrad_rows_kernel<MFT, SS, BB, NS>), grid, dim3(512), lds, s, a, ab, bb)
-        if (s_ == 1 && bca == 64)       { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 64, 3);  else SBG_ROWS_LAUNCH(f16_mfma, 1, 64, 3); }
-        else if (s_ == 1)               { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 1, 128, 3); else SBG_ROWS_LAUNCH(f16_mfma, 1, 128, 3); }
-        else if (bca == 64)             { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 64, 3);  else SBG_ROWS_LAUNCH(f16_mfma, 2, 64, 3); }
-        else if (nst == 2)              { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 128, 2); else SBG_ROWS_LAUNCH(f16_mfma, 2, 128, 2); }
-        else                            { if (bf) SBG_ROWS_LAUNCH(bf16_mfma, 2, 128, 3); else SBG_ROWS_LAUNCH(f16_mfma, 2, 128, 3); }
+#define SBG_ROWS_LAUNCH(MFT, SS, BB, NS) do { auto kern = conv_wgrad_rows_kernel<MFT, SS, BB, NS>; \
+        if (lds > 64 * 1024 && !SBG_RAISE_LDS_ONCE(kern, lds)) return sbg_fail(SBG_ERR_LAUNCH, "conv2d_wgrad: cannot raise the dynamic LDS limit to %d bytes", lds); \
+        SBG_LAUNCH(kern, grid, dim3(512), lds, s, a, ab, bb); } while (0)
+#define SBG_ROWS_NS(MFT, SS, BB) do { switch (nst) { case 2: SBG_ROWS_LAUNCH(MFT, SS, BB, 2); break; case 3: SBG_ROWS_LAUNCH(MFT, SS, BB, 3); break; \
+        case 4: SBG_ROWS_LAUNCH(MFT, SS, BB, 4); break; case 5: SBG_ROWS_LAUNCH(MFT, SS, BB, 5); break; default: SBG_ROWS_LAUNCH(MFT, SS, BB, 6); break; } } while (0)
+        if (s_ == 1 && bca == 64)       { if (bf) SBG_ROWS_NS(bf16_mfma, 1, 64);  else SBG_ROWS_NS(f16_mfma, 1, 64); }
+        else if (s_ == 1)               { if (bf) SBG_ROWS_NS(bf16_mfma, 1, 128); else SBG_ROWS_NS(f16_mfma, 1, 128); }
+        else if (bca == 64)             { if (bf) SBG_ROWS_NS(bf16_mfma, 2, 64);  else SBG_ROWS_NS(f16_mfma, 2, 64); }
+        else                            { if (bf) SBG_ROWS_NS(bf16_mfma, 2, 128); else SBG_ROWS_NS(f16_mfma, 2, 128); }
+#undef SBG_ROWS_NS
 #undef SBG_ROWS_LAUNCH
         SBG_HIP_LAUNCH_CHECK();
     } else if (use_big_tile(a.ntaps)) {

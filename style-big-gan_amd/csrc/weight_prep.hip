@@ -231,6 +231,50 @@ __global__ __launch_bounds__(256) void split_bf16_cat_kernel(SplitArgs a)
         for (int s = 0; s < a.nseg; s++) dst[(int64_t)s * a.C * a.inner] = part[a.order[s]];
     }
 }
+
+// the same split of a STRIDED 4-D view, written densely in the view's own dimension order (a permuted weight view -> the packed
+// [tap][cout][parts x cin] operand in one pass, instead of a split in memory order followed by a transposing copy of six times the data)
+struct SplitNdArgs { const float* x; unsigned short* y; int64_t total; int64_t shape[4], xs[4]; int cat; int nseg; int order[8]; };
+
+__global__ __launch_bounds__(256) void split_bf16_cat_nd_kernel(SplitNdArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.total; idx += stride) {
+        int64_t d[4], r = idx;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) { d[k] = r % a.shape[k]; r /= a.shape[k]; }
+        float v = a.x[d[0] * a.xs[0] + d[1] * a.xs[1] + d[2] * a.xs[2] + d[3] * a.xs[3]];
+        unsigned short part[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { part[k] = f32_to_bf16_bits(v); v -= bf16_bits_to_f32(part[k]); }
+        int64_t off = 0, seg = 1;                            // dense output offset of (d, part 0); distance between parts
+#pragma unroll
+        for (int k = 0; k < 4; k++) off = off * (k == a.cat ? a.shape[k] * a.nseg : a.shape[k]) + d[k];
+#pragma unroll
+        for (int k = 3; k >= 0; k--) { if (k == a.cat) { seg *= a.shape[k]; break; } seg *= a.shape[k]; }
+        for (int s = 0; s < a.nseg; s++) a.y[off + (int64_t)s * seg] = part[a.order[s]];
+    }
+}
+}
+
+extern "C" int sbg_split_bf16_cat_nd(const float* x, const int64_t* shape, const int64_t* xstrides, int cat_dim, void* y, int nseg, const int* order,
+                                     sbg_stream_t stream_)
+{
+    SBG_CHECK(x && y && order && shape && xstrides, "split_bf16_cat_nd: null pointer");
+    SBG_CHECK(cat_dim >= 0 && cat_dim < 4 && nseg >= 1 && nseg <= 8, "split_bf16_cat_nd: bad sizes");
+    SplitNdArgs a;
+    a.x = x; a.y = (unsigned short*)y; a.cat = cat_dim; a.nseg = nseg; a.total = 1;
+    for (int k = 0; k < 4; k++) {
+        SBG_CHECK(shape[k] >= 0 && xstrides[k] >= 0, "split_bf16_cat_nd: negative extent or stride");
+        a.shape[k] = shape[k]; a.xs[k] = xstrides[k]; a.total *= shape[k];
+    }
+    for (int s = 0; s < 8; s++) { a.order[s] = s < nseg ? order[s] : 0; SBG_CHECK(a.order[s] >= 0 && a.order[s] <= 2, "split_bf16_cat_nd: part index out of range"); }
+    if (a.total == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 0.0, (double)a.total * (4.0 + 2.0 * nseg), {(int)shape[0], (int)shape[1], (int)shape[2], 5, nseg, (int)shape[3], 0});
+    SBG_LAUNCH(split_bf16_cat_nd_kernel, dim3(sbg_stream_grid(a.total, 256)), dim3(256), 0, stream, a);
+    SBG_HIP_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int sbg_split_bf16_cat(const float* x, void* y, int64_t outer, int64_t C, int64_t inner, int nseg, const int* order, sbg_stream_t stream_)

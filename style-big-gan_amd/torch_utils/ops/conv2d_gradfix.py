@@ -131,10 +131,20 @@ _ORDER6 = ((2, 0, 1, 1, 0, 0), (0, 2, 1, 0, 1, 0))      # part indices of (a, b)
 _ORDER3 = ((1, 0, 0), (0, 1, 0))
 
 
-def _split_cat(t, dim, order):
+def _split_cat(t, dim, order, dense=False):
     """fp32 `t` -> bf16 tensor with `len(order)` times the size along `dim`: the hi / mid / lo parts `order[s]` of t side by side, in ONE
-    kernel (sbg_split_bf16_cat).  The result keeps t's memory order (channel-minor stays channel-minor)."""
+    kernel.  By default the result keeps t's memory order (channel-minor stays channel-minor: sbg_split_bf16_cat); `dense` asks for a
+    contiguous result whatever t's strides are (sbg_split_bf16_cat_nd: a permuted weight view becomes the packed operand without the
+    transposing copy of six times the data that `.contiguous()` would add)."""
     import ctypes
+    arr = (ctypes.c_int * len(order))(*order)
+    if dense and t.ndim <= 4 and not t.is_contiguous():
+        lead = 4 - t.ndim
+        shape = [1] * lead + list(t.shape)
+        out = torch.empty([len(order) * n if d == dim else n for d, n in enumerate(t.shape)], dtype=torch.bfloat16, device=t.device)
+        _lib.check(_lib.load().sbg_split_bf16_cat_nd(_lib.ptr(t), (ctypes.c_int64 * 4)(*shape), (ctypes.c_int64 * 4)(*([0] * lead + list(t.stride()))),
+                                                     lead + dim, _lib.ptr(out), len(order), arr, _lib.stream_ptr(t.device)), "sbg_split_bf16_cat_nd")
+        return out
     perm = sorted(range(t.ndim), key=lambda d: (-t.stride(d), d))
     tt = t.permute(perm)
     if not tt.is_contiguous():
@@ -143,18 +153,17 @@ def _split_cat(t, dim, order):
     outer = int(np.prod(tt.shape[:k], dtype=np.int64)) if k > 0 else 1
     C, inner = tt.shape[k], (int(np.prod(tt.shape[k + 1:], dtype=np.int64)) if k + 1 < tt.ndim else 1)
     out = torch.empty(list(tt.shape[:k]) + [len(order) * C] + list(tt.shape[k + 1:]), dtype=torch.bfloat16, device=t.device)
-    arr = (ctypes.c_int * len(order))(*order)
     _lib.check(_lib.load().sbg_split_bf16_cat(_lib.ptr(tt), _lib.ptr(out), outer, C, inner, len(order), arr, _lib.stream_ptr(t.device)), "sbg_split_bf16_cat")
     inv = [perm.index(d) for d in range(t.ndim)]
     return out.permute(inv)
 
 
-def _mfma_operands(a, b, a_cat_dim, b_cat_dim):
+def _mfma_operands(a, b, a_cat_dim, b_cat_dim, b_dense=False):
     """[(a_k, b_k)]: the matrix-core launches whose sum is the product of a and b (see _operand_passes); small fp32 operands become ONE launch
-    over concatenated hi / mid / lo parts, each operand built by one kernel"""
+    over concatenated hi / mid / lo parts, each operand built by one kernel (`b_dense`: b is a weight view wanted contiguous)"""
     if (a.dtype == torch.float32 and b.dtype == torch.float32 and a.device.type == "cuda" and a.numel() <= CONCAT_NUMEL and a.numel() > 0 and b.numel() > 0):
         oa, ob = _ORDER6 if fp32_mfma_passes >= 6 else _ORDER3
-        return [(_split_cat(a, a_cat_dim, oa), _split_cat(b, b_cat_dim, ob))]
+        return [(_split_cat(a, a_cat_dim, oa), _split_cat(b, b_cat_dim, ob, dense=b_dense))]
     return _fold_passes(_operand_passes(a, b), a_cat_dim, b_cat_dim)
 
 
@@ -349,7 +358,7 @@ def _conv_forward(x, w, stride, padding, epi=None, wgain=1.0):
         wpk = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
         if xp.shape[1] != cin:
             wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
-        passes = _mfma_operands(xp, wpk, 1, 2)
+        passes = _mfma_operands(xp, wpk, 1, 2, b_dense=True)
     multi = len(passes) > 1 or len(taps) > _lib.SBG_MAX_TAPS
     y = torch.empty([n, cout, oh, ow], dtype=torch.float32 if multi else x.dtype, device=x.device, memory_format=torch.channels_last)
     assert epi is None or (not multi)
@@ -381,7 +390,7 @@ def _conv_transpose_forward(x, w, stride, padding, output_padding, wgain=1.0):
         wpk = w.permute(2, 3, 1, 0).reshape(kh * kw, cout, cin)
         if xp.shape[1] != cin:
             wpk = torch.nn.functional.pad(wpk, (0, xp.shape[1] - cin))
-        passes = _mfma_operands(xp, wpk, 1, 2)
+        passes = _mfma_operands(xp, wpk, 1, 2, b_dense=True)
     # phases: output rows oy = s*o + a use taps kh == (a + p) mod s with input row o + (a + p - kh) / s
     phases = []
     need_zero = False

@@ -242,6 +242,22 @@ def test_conv2d_split_k(dev):
         check(got, ref, 2e-2, f"split-K conv + fused {act}")
 
 
+def test_split_bf16_cat_dense_of_strided_view(dev):
+    """sbg_split_bf16_cat_nd on a permuted weight view == the memory-order split followed by .contiguous(), bit for bit; the parts sum back
+    to the fp32 value within 2^-24 relative"""
+    torch.manual_seed(3)
+    w = torch.randn(24, 13, 3, 3, device=dev)
+    view = w.permute(2, 3, 0, 1).reshape(9, 24, 13)                        # [tap, cout, cin]: a strided view of the parameter
+    assert not view.is_contiguous()
+    for order in (conv2d_gradfix._ORDER6[1], (0, 1, 2)):
+        for dim in (2, 1):
+            dense = conv2d_gradfix._split_cat(view, dim, order, dense=True)
+            plain = conv2d_gradfix._split_cat(view, dim, order).contiguous()
+            assert dense.is_contiguous() and dense.shape == plain.shape and torch.equal(dense, plain)
+    parts = conv2d_gradfix._split_cat(view, 2, (0, 1, 2), dense=True).float().reshape(9, 24, 3, 13).sum(2)
+    assert float((parts - view).abs().max()) <= 2.0 ** -22 * float(view.abs().max())
+
+
 def test_conv2d_large_k_and_many_pixels(dev):
     # enough pixels that the weight-gradient kernel splits the pixel axis across workgroups
     _conv_case(dev, torch.bfloat16, 4, 64, 64, 64, 64, 3, 1, 1, False)
