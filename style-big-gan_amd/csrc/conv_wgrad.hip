@@ -17,8 +17,8 @@
 // every tap, only the gathered b-tiles change.  The pixel axis is split over gridDim.z workgroups that write fp32
 // partial slabs; a second kernel sums the slabs in a fixed order (bitwise reproducible, no float atomics).
 #include "sbg_common.h"
+#include "lds_asm.h"
 #include <cstdlib>
-#include <utility>
 
 namespace {
 
@@ -73,23 +73,6 @@ static __device__ __forceinline__ short4_t lds_tr_read(const unsigned char* p)
 {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p));
 }
-
-// the same read as inline assembly (the compiler neither schedules it nor counts it: pair with lds_wait), and the wait that hands the
-// registers back to the compiler: "+v" makes every later use of the fragment depend on the s_waitcnt
-template <int OFF>
-static __device__ __forceinline__ void lds_tr_issue(short4_t& d, unsigned addr)
-{
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int N>
-static __device__ __forceinline__ void lds_wait(short4_t& a, short4_t& b)
-{
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
-}
-template <class F, int... Is>
-static __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N, class F>
-static __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 template <class MF, int BCA, int BCB, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p)
@@ -378,7 +361,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
 #pragma unroll
             for (int i = 0; i < 3; i++) blo[i] = bhi[i] = short4_t{(short)s, 3, 2, 1};
         }
-        static_for<TA>([&](auto it) {
+        sbg_static_for<TA>([&](auto it) {
             constexpr int i = decltype(it)::value;
             if constexpr ((ABL & 4) == 0) {
                 lds_tr_issue<0>(alo[i], stage + (unsigned)offA[i]);
@@ -397,7 +380,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         };
         issue_b(std::integral_constant<int, 0>{});
         issue_b(std::integral_constant<int, 1>{});
-        static_for<9>([&](auto tt) {
+        sbg_static_for<9>([&](auto tt) {
             constexpr int t = decltype(tt)::value;
             if constexpr (t + 2 < 9) issue_b(std::integral_constant<int, t + 2>{});
             if constexpr ((ABL & 4) == 0)

@@ -13,6 +13,7 @@
 //  * planar (NCHW) activations: one lane = one output pixel of one channel, lanes walk x (coalesced along rows).
 //  * the filter lives in LDS (<= 1024 taps) and is read with wave-uniform addresses (broadcast, conflict-free).
 #include "sbg_common.h"
+#include "lds_asm.h"
 #include <cstdlib>
 
 namespace {
@@ -455,18 +456,26 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
     fetch_rows(0, SR + FH - 1);
 
     const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
+    const unsigned lds_base = (unsigned)(uintptr_t)((fir_lds_ptr)fsm);
     short8_t bt[FH];
+    {   // the sixteen taps first (uniform addresses, all in flight together), then the per-lane band matrix by selection: written as a load
+        // under the lane's own condition this was 32 dependent load -> wait round trips at the head of every workgroup
+        float taps[FH][FW];
 #pragma unroll
-    for (int ky = 0; ky < FH; ky++) {
-        const int fy = p.flip ? ky : FH - 1 - ky;
+        for (int ky = 0; ky < FH; ky++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int kpix = j < 4 ? 4 * fg + j : 16 + 4 * fg + (j - 4);
-            const int kx = kpix - fi;
-            float v = 0.f;
-            if (kx >= 0 && kx < FW) v = p.f[fy * p.fsy + (p.flip ? kx : FW - 1 - kx) * p.fsx];
-            bt[ky][j] = FirMfma<T>::bits(v);
-        }
+            for (int kx = 0; kx < FW; kx++) taps[ky][kx] = p.f[(p.flip ? ky : FH - 1 - ky) * p.fsy + (p.flip ? kx : FW - 1 - kx) * p.fsx];
+#pragma unroll
+        for (int ky = 0; ky < FH; ky++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int kpix = j < 4 ? 4 * fg + j : 16 + 4 * fg + (j - 4);
+                const int kx = kpix - fi;
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < FW; q++) v = (kx == q) ? taps[ky][q] : v;
+                bt[ky][j] = FirMfma<T>::bits(v);
+            }
     }
     // the swizzle of an LDS row depends on (R >> 1) & 3 with R = slot * 48 + pixel: 48 is a multiple of 8, so the offsets are slot-independent
     int offA[4];
@@ -480,12 +489,14 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
     float4_t t_scale[4], t_bias[4];
     const float t_alpha = p.tail ? p.alpha : 1.f, t_gain = p.tail ? p.act_gain : 1.f, t_cl = (p.tail && p.clamp >= 0.f) ? p.clamp : __builtin_inff();
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int ch = cb0 * 64 + c * 16 + 4 * fg;
-        t_scale[c] = float4_t{p.gain, p.gain, p.gain, p.gain};
-        t_bias[c] = float4_t{0.f, 0.f, 0.f, 0.f};
-        if (p.tail && p.oscale) t_scale[c] *= *reinterpret_cast<const float4_t*>(p.oscale + (int64_t)n * p.C + ch);
-        if (p.tail && p.bias)   t_bias[c] = *reinterpret_cast<const float4_t*>(p.bias + ch);
+    for (int c = 0; c < 4; c++) { t_scale[c] = float4_t{p.gain, p.gain, p.gain, p.gain}; t_bias[c] = float4_t{0.f, 0.f, 0.f, 0.f}; }
+    if (p.tail && p.oscale) {           // (one branch per tensor: its four loads are in flight together)
+#pragma unroll
+        for (int c = 0; c < 4; c++) t_scale[c] *= *reinterpret_cast<const float4_t*>(p.oscale + (int64_t)n * p.C + cb0 * 64 + c * 16 + 4 * fg);
+    }
+    if (p.tail && p.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) t_bias[c] = *reinterpret_cast<const float4_t*>(p.bias + cb0 * 64 + c * 16 + 4 * fg);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -497,21 +508,32 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
         for (int sg = 0; sg < 2; sg++)
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[sg][c] = float4_t{0.f, 0.f, 0.f, 0.f};
+        // Reads by inline assembly (lds_asm.h): behind the LDS-DMA prefetch just issued, builtin reads get a compiler-inserted vmcnt(0) and the
+        // prefetch would be waited for before the first MFMA of the step.  Eight groups (filter row ky, pixel half sg) of eight reads, the next
+        // group in flight while the current one multiplies.
+        unsigned rowa[FH];
 #pragma unroll
-        for (int ky = 0; ky < FH; ky++) {
-            const int slot = (SR * s + wave + ky) % RING;
-            const unsigned char* rowp = fsm + (slot * WXL) * 128;
+        for (int ky = 0; ky < FH; ky++) rowa[ky] = lds_base + (unsigned)((((SR * s + wave + ky) % RING) * WXL) * 128);
+        short4_t lo[2][4], hi[2][4];
+        auto issue_grp = [&](auto gt) {
+            constexpr int g = decltype(gt)::value, ky = g >> 1, sg = g & 1;
+            sbg_static_for<4>([&](auto ct) {
+                constexpr int c = decltype(ct)::value;
+                lds_tr_issue<sg * 16 * 128>(lo[g & 1][c], rowa[ky] + (unsigned)offA[c]);
+                lds_tr_issue<sg * 16 * 128 + 16 * 128>(hi[g & 1][c], rowa[ky] + (unsigned)offA[c]);
+            });
+        };
+        issue_grp(std::integral_constant<int, 0>{});
+        sbg_static_for<8>([&](auto gt) {
+            constexpr int g = decltype(gt)::value, ky = g >> 1, sg = g & 1;
+            if constexpr (g + 1 < 8) issue_grp(std::integral_constant<int, g + 1>{});
+            lds_wait<(g + 1 < 8 ? 8 : 0)>(lo[g & 1], hi[g & 1]);
 #pragma unroll
-            for (int sg = 0; sg < 2; sg++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const unsigned char* q = rowp + sg * 16 * 128 + offA[c];
-                    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fir_lds_s4_ptr)q);
-                    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fir_lds_s4_ptr)(q + 16 * 128));
-                    const short8_t fa = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc[sg][c] = FirMfma<T>::run(fa, bt[ky], acc[sg][c]);
-                }
-        }
+            for (int c = 0; c < 4; c++) {
+                const short8_t fa = {lo[g & 1][c][0], lo[g & 1][c][1], lo[g & 1][c][2], lo[g & 1][c][3], hi[g & 1][c][0], hi[g & 1][c][1], hi[g & 1][c][2], hi[g & 1][c][3]};
+                acc[sg][c] = FirMfma<T>::run(fa, bt[ky], acc[sg][c]);
+            }
+        });
         const int oy = oy_begin + SR * s + wave;
         // fused tail in fp32, then pack to 16-bit pairs
         unsigned pk[2][4][2];
