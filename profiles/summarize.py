@@ -42,6 +42,8 @@ def log_family(rec):
             return 'conv_k64_kernel'
         if top == 6 and rem < 1000:
             return 'conv_thin_kernel'
+        if top == 9:
+            return 'conv_up2_kernel'
         return 'conv_gather_ld_kernel' if top >= 4 else None
     if rec['kind'] == 'conv_wgrad':
         return 'conv_wgrad_rows_kernel' if code >= 1000000 else None      # the generic weight-gradient kernel launches once per tap group: not joined

@@ -50,3 +50,6 @@ int sbg_conv_k64_dispatch(sbgconv::ConvArgs& a, bool bf16, int64_t x_bytes, int6
 // conv_thin.hip: few-channel convolutions (Cin, Cout <= 64, one of them <= 32) as a streaming kernel with the reduction axis packed
 // over (tap, channel).  Returns SBG_OK / an error, or -1 when the launch is not a thin one.
 int sbg_conv_thin_dispatch(sbgconv::ConvArgs& a, bool bf16, hipStream_t stream);
+// conv_up2.hip: all four phases of a stride-2 3x3 transposed convolution from one staged input halo.  Returns SBG_OK / an error, or -1 when the
+// launch is not of that form; on SBG_OK `border` describes the remaining last row / column rectangles as an ordinary phased launch.
+int sbg_conv_up2_dispatch(sbgconv::ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, sbg_conv_params* border, const sbg_conv_params* q, hipStream_t stream);

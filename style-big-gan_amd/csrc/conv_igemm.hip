@@ -462,6 +462,14 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
             if (rc >= 0) return rc;
             a.nphase = 1;
         }
+        if (allow_dma && q->nphase == 4) {      // stride-2 3x3 transposed convolution: every phase from one staged halo (conv_up2.hip), then its border
+            a.nphase = 4;
+            sbg_conv_params border;
+            const int rc = sbg_conv_up2_dispatch(a, q->xdtype == SBG_BF16, x_bytes, w_bytes, &border, q, s);
+            if (rc > 0) return rc;
+            if (rc == SBG_OK) return border.nphase > 0 ? sbg_conv2d_igemm(&border, stream) : SBG_OK;
+            a.nphase = 1;
+        }
         const int64_t tiles = ((ptot / q->nphase + 255) / 256) * q->nphase * ((q->Cout + 127) / 128);
         if (allow_dma && q->Cout > 64 && tiles >= phase_min_tiles() && x_bytes < (int64_t)0x80000000u && w_bytes < (int64_t)0x80000000u && sbg_env("SBG_CONV_NO_PHASES") == nullptr) {
             a.nphase = q->nphase;
