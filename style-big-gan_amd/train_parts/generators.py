@@ -114,12 +114,64 @@ class FullyConnectedLayer(torch.nn.Module):
             b = b.to(x.dtype)
             if self.bias_gain != 1:
                 b = b * self.bias_gain
+        w = self.weight.to(x.dtype)
         if self.activation == 'linear' and b is not None:
-            # b + weight_gain * (x @ W^T): the gain rides in the GEMM's alpha (forward and both backward products) instead of a pass over W
-            # per call -- twenty affine layers per synthesis pass, each a [C, 512] multiply forward and another one backward otherwise
-            return torch.addmm(b.unsqueeze(0), x, self.weight.to(x.dtype).t(), alpha=float(self.weight_gain))
-        w = self.weight.to(x.dtype) * self.weight_gain
-        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+            return _scaled_linear(x, w, b, float(self.weight_gain))
+        return bias_act.bias_act(_scaled_linear(x, w, None, float(self.weight_gain)), b, act=self.activation)
+
+
+_zero_cache = {}
+
+
+def _zero(like):
+    """a one-element zero tensor per (device, dtype): the ignored `input` of addmm(..., beta=0)"""
+    key = (like.device, like.dtype)
+    z = _zero_cache.get(key)
+    if z is None:
+        z = _zero_cache[key] = torch.zeros([1], device=like.device, dtype=like.dtype)
+    return z
+
+
+class _ScaledLinear(torch.autograd.Function):
+    """y = b + alpha * x @ W^T with the gain in the GEMM's alpha, forward and in both backward products (reference: `w = weight * weight_gain`
+    then addmm / matmul, train_parts/generators.py:117-127 -- a pass over W per call, and autograd's backward of it is mm, mul, mm, mul).
+    First-order calls run three kernels backward (two GEMMs, the bias sum); when a graph is being built (R1, path length) the backward is the
+    differentiable composition of the same products."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, alpha):
+        ctx.save_for_backward(x, w)
+        ctx.alpha = alpha
+        ctx.has_bias = b is not None
+        if b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t(), alpha=alpha)
+        return torch.addmm(_zero(x), x, w.t(), beta=0, alpha=alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        alpha = ctx.alpha
+        dx = dw = db = None
+        if torch.is_grad_enabled():
+            if ctx.needs_input_grad[0]:
+                dx = g.mm(w) * alpha
+            if ctx.needs_input_grad[1]:
+                dw = g.t().mm(x) * alpha
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = torch.addmm(_zero(g), g, w, beta=0, alpha=alpha)
+            if ctx.needs_input_grad[1]:
+                dw = torch.addmm(_zero(g), g.t(), x, beta=0, alpha=alpha)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(0)
+        return dx, dw, db, None
+
+
+def _scaled_linear(x, w, b, alpha):
+    if x.ndim != 2 or x.device.type != 'cuda':
+        y = x.matmul(w.t()) * alpha                      # (host tensors, unusual ranks: the plain composition)
+        return y if b is None else y + b
+    return _ScaledLinear.apply(x, w, b, alpha)
 
 
 class Conv2dLayer(torch.nn.Module):

@@ -242,6 +242,21 @@ def test_conv2d_split_k(dev):
         check(got, ref, 2e-2, f"split-K conv + fused {act}")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_conv_transpose_stride2_one_pass_kernel(dev, dtype):
+    """stride-2 3x3 transposed convolutions whose phase grids are multiples of 8 x 32 (+ 1): conv_up2_kernel writes the 8 x 32 tiles of all
+    four phases, the last row / column go through the gather launch; ragged channel counts on both sides; forward, dx (a stride-2
+    convolution) and dw against the oracle.  The launch log must show the kernel was the one that ran."""
+    from style_big_gan_amd import _lib
+    _lib.prof_enable(True); _lib.prof_fetch()
+    _conv_case(dev, dtype, 2, 64, 64, 8, 32, 3, 2, 0, True)          # one tile per image, 17 x 65 out
+    _conv_case(dev, dtype, 1, 96, 72, 24, 32, 3, 2, 0, True)         # Cin = 1.5 slices, Cout = 64 + 8
+    _conv_case(dev, dtype, 2, 128, 136, 16, 64, 3, 2, 0, True)       # two tiles across, three channel tiles
+    _lib.prof_enable(False)
+    codes = [r["dims"][6] for r in _lib.prof_fetch() if r["kind"] == "conv_igemm"]
+    assert sum(c // 1000000 == 9 for c in codes) >= 3, codes
+
+
 def test_split_bf16_cat_dense_of_strided_view(dev):
     """sbg_split_bf16_cat_nd on a permuted weight view == the memory-order split followed by .contiguous(), bit for bit; the parts sum back
     to the fp32 value within 2^-24 relative"""
