@@ -127,7 +127,7 @@ def summarize_kernels(records):
 
 
 # kernel kind of the launch log -> kernel names in the rocprofv3 traces
-PMC_KERNELS = {'conv_igemm': ('conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel', 'conv_up_fir_kernel'),
+PMC_KERNELS = {'conv_igemm': ('conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel', 'conv_up2_kernel', 'conv_thin_kernel'),
                'conv_wgrad': ('conv_wgrad_rows_kernel', 'conv_wgrad_kernel'), 'upfirdn2d': ('upfirdn2d_fir', 'upfirdn2d_kernel'),
                'bias_act': ('bias_act',), 'scale_nc': ('scale_nc',), 'dot_hw': ('dot_hw',)}
 

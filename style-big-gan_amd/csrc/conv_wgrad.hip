@@ -295,9 +295,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
                 const int q = piece - APIECES;                 // patch piece; q >= 3 * PPR are spares (zeros)
                 const int r = q / PPR, jb = q - r * PPR;
                 const int R = r * PROW + jb * 8 + drow;        // LDS row inside the patch
-                const int by = S * py + dy0 + r, bx = S * px0 + dx0 + jb * 8 + drow;
+                // stride 2: the patch row is stored de-interleaved -- its 33 even columns in LDS rows 0..39, the 32 odd ones in rows 40..71 -- so
+                // that the 32 pixels a tap reads (columns dx + 2 p) are CONSECUTIVE LDS rows, like at stride 1.  Interleaved, the eight rows of a
+                // transposing read all had one parity, i.e. one 32-bank half: two-way conflicts on every b read (SQ_LDS_BANK_CONFLICT 41 % of
+                // the LDS cycles, profiles/r02d_sq_counters.json).
+                constexpr int NEVEN = (PCOLS + 1) / 2, EVROWS = ((NEVEN + 7) / 8) * 8;
+                const int pcol = (S == 1) ? jb * 8 + drow : (jb * 8 < EVROWS ? 2 * (jb * 8 + drow) : 2 * (jb * 8 - EVROWS + drow) + 1);
+                const int by = S * py + dy0 + r, bx = S * px0 + dx0 + pcol;
                 const int ch = cb0 + src_chunk(R) * 8;
-                const unsigned okm = 0u - (unsigned)((q < 3 * PPR) & ((unsigned)by < (unsigned)p.BH) & ((unsigned)bx < (unsigned)p.BW) & (ch < p.Cb));
+                const unsigned okm = 0u - (unsigned)((q < 3 * PPR) & (pcol < PCOLS) & ((unsigned)by < (unsigned)p.BH) & ((unsigned)bx < (unsigned)p.BW) & (ch < p.Cb));
                 const unsigned real = (unsigned)(n * (int)p.bs_n + by * (int)p.bs_h + bx * (int)p.bs_w + ch) * 2u;
                 unsigned char* dst = (q < 3 * PPR) ? st + A_BYTES + q * 1024 : smem + DUMP;      // (wave-uniform)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_void_ptr)dst, 16, (real & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
@@ -316,7 +322,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
 
     // Per-lane LDS byte offsets of the transposing reads, computed once.  The tap order is fixed (t = 3 i + j), so inside the
     // chunk loop every read is `per-lane base (one of 3 column-tap variants) + compile-time constant`.
-    // For patch row R = PROW*i + j + S*(4g + q) (and R + 16 S) the swizzle term (R >> 1) & 3 depends on j only (PROW % 8 == 0).
+    // The 32 pixels of tap column j are the consecutive patch rows PROW*i + base(j) + p (stride 2: columns de-interleaved, base(j) = 40 (j & 1)
+    // + (j >> 1)), so the swizzle term (R >> 1) & 3 depends on j only (PROW and 40 are multiples of 8).
     auto frag_off = [&](int Rrel, int col) {
         const int chunk = (col >> 3) + (fp >> 1);
         const int sw = (((chunk >> 1) ^ ((Rrel >> 1) & 3)) << 1) | (chunk & 1);
@@ -329,7 +336,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
         offA[i] = (col >> 6) * 4096 + frag_off(4 * fg + fq, col & 63);
     }
 #pragma unroll
-    for (int d = 0; d < 3; d++) offB[d] = frag_off(d + S * (4 * fg + fq), wb);
+    for (int d = 0; d < 3; d++) {
+        constexpr int EVROWS_ = (((PCOLS + 1) / 2 + 7) / 8) * 8;
+        offB[d] = frag_off((S == 1 ? d : (d & 1) * EVROWS_ + (d >> 1)) + 4 * fg + fq, wb);      // stride 2: de-interleaved columns (see issue())
+    }
     auto read_frag = [&](const unsigned char* base, int off, int hi_off) -> short8_t {
         short4_t lo = lds_tr_read(base + off), hi = lds_tr_read(base + off + hi_off);
         return short8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
             constexpr int t = decltype(tt)::value, dyi = t / 3, dxi = t % 3, OFF = A_BYTES + dyi * PROW * 128;
             if constexpr ((ABL & 4) == 0) {
                 lds_tr_issue<OFF>(blo[t % 3], pb[dxi]);
-                lds_tr_issue<OFF + S * 16 * 128>(bhi[t % 3], pb[dxi]);
+                lds_tr_issue<OFF + 16 * 128>(bhi[t % 3], pb[dxi]);
             }
         };
         issue_b(std::integral_constant<int, 0>{});
