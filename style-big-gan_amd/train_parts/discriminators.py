@@ -267,6 +267,26 @@ class Discriminator(torch.nn.Module):
         ek.update(in_channels=channels[4], cmap_dim=cmap_dim, resolution=4)
         ek.update(common)
         self.b4 = DiscriminatorEpilogue(**ek)
+        # one forward over [fake; real] computes what two forwards compute when nothing in the network carries state across calls (spectral-norm
+        # power iterations do: the attention blocks) and the minibatch-std groups are kept apart -- see merged_batch_order()
+        self.batch_mergeable = len(tuple(attentions)) == 0
+
+    def merged_batch_order(self, n):
+        """index tensor (host list) that arranges cat([a, b]) (n samples each) so that the minibatch-std groups of the merged batch are exactly
+        the groups the layer forms on a and on b alone (reference MinibatchStdLayer :316-328 groups samples j, j + n/G, j + 2 n/G, ...), or
+        None when the two halves cannot be kept apart.  Position p = r + (2 n / G) k holds a[r + (n/G) k] for r < n/G, else b[r - n/G + (n/G) k]."""
+        mb = self.b4.mbstd
+        if mb is None:
+            return list(range(2 * n))
+        G = min(int(mb.group_size), n) if mb.group_size is not None else None
+        if G is None or n % G != 0 or min(int(mb.group_size), 2 * n) != G:
+            return None
+        m = n // G
+        order = []
+        for p in range(2 * n):
+            k, r = divmod(p, 2 * m)
+            order.append(r + m * k if r < m else n + (r - m) + m * k)
+        return order
 
     def forward(self, img, c, **block_kwargs):
         x = None

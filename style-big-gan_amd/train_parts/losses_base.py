@@ -34,6 +34,10 @@ losses_arch = utils.ClassRegistry()
 
 _scope = torch.autograd.profiler.record_function
 
+import os as _os
+merge_d_passes = _os.environ.get('SBG_MERGE_D', '1') != '0'      # Dmain: one discriminator pass over [generated; real] (see _pass_d_adv)
+_order_cache = {}
+
 #             phase      passes, in execution order
 _PROGRAMS = {'Gmain': ('g_adv',), 'Greg': ('g_reg',), 'Gboth': ('g_adv', 'g_reg'),
              'Dmain': ('d_adv',), 'Dreg': ('d_reg',), 'Dboth': ('d_adv', 'd_reg')}
@@ -112,14 +116,59 @@ class LossBase:
         """discriminator's loss on generated and real images; one backward covers both forwards (reference :64-81)"""
         with _scope('Dgen_forward'):
             gen_img = self.run_G(rnd.gen_z, rnd.gen_c, sync=False)          # G's parameters do not require grad in a D phase: no graph
-            gen_logits = self.run_D(gen_img, rnd.gen_c, sync=False)          # exchanged together with the real pass below
+            order = None if reg_follows else self._merged_order(gen_img, rnd)
+            if order is not None:
+                gen_logits, rnd.real_logits = self._run_D_merged(gen_img, rnd, order, sync=(rnd.sync and closes_round))
+            else:
+                gen_logits = self.run_D(gen_img, rnd.gen_c, sync=False)      # exchanged together with the real pass below
+                rnd.real_img_tmp = rnd.real_img.detach().requires_grad_(reg_follows)
+                rnd.real_logits = self.run_D(rnd.real_img_tmp, rnd.real_c, sync=(rnd.sync and closes_round))
             _report_scores('fake', gen_logits)
-            rnd.real_img_tmp = rnd.real_img.detach().requires_grad_(reg_follows)
-            rnd.real_logits = self.run_D(rnd.real_img_tmp, rnd.real_c, sync=(rnd.sync and closes_round))
             _report_scores('real', rnd.real_logits)
             loss_Dgen = self.loss.calc_loss(rnd.real_logits, gen_logits)
         with _scope('Dgen_backward'):      # a regulariser of the same phase differentiates real_logits again: keep the graph for it
             loss_Dgen.mean().mul(rnd.gain).backward(retain_graph=reg_follows)
+
+    # One discriminator pass over [generated; real] instead of two (the reference runs D twice, :66-77).  Same function values and the same
+    # parameter gradients up to summation order: the augmentation pipe still sees the two halves in the reference's order (its random draws
+    # are consumed identically), and the samples are interleaved so that the minibatch-std layer forms exactly the groups it forms on each
+    # half alone (Discriminator.merged_batch_order).  Only for a plain Dmain (no regulariser differentiating the reals in this phase) and for
+    # discriminators that declare `batch_mergeable` (no state carried across forward calls).  Worth it because the fixed cost of a pass --
+    # ~600 launches, the latency-bound 4x4 ... 32x32 layers -- is paid once: see DESIGN.md, "passes per round".
+    def _merged_order(self, gen_img, rnd):
+        if not merge_d_passes:
+            return None
+        d = getattr(self.D, 'module', self.D)
+        if not getattr(d, 'batch_mergeable', False) or gen_img.shape != rnd.real_img.shape:
+            return None
+        if (rnd.gen_c is None) != (rnd.real_c is None) or (rnd.gen_c is not None and rnd.gen_c.shape != rnd.real_c.shape):
+            return None
+        n = gen_img.shape[0]
+        key = (id(d), n, gen_img.device)
+        hit = _order_cache.get(key)
+        if hit is None:
+            order = d.merged_batch_order(n)
+            if order is None:
+                hit = (None, None)
+            else:
+                fwd = torch.tensor(order, dtype=torch.int64, device=gen_img.device)
+                inv = torch.empty_like(fwd)
+                inv[fwd] = torch.arange(2 * n, device=gen_img.device)
+                hit = (fwd, inv)
+            _order_cache[key] = hit
+        return hit if hit[0] is not None else None
+
+    def _run_D_merged(self, gen_img, rnd, order, sync):
+        fwd, inv = order
+        n = gen_img.shape[0]
+        real = rnd.real_img.detach()
+        if self.augment_pipe is not None:
+            gen_img, real = self.augment_pipe(gen_img), self.augment_pipe(real)
+        x = torch.cat([gen_img, real.to(gen_img.dtype)]).index_select(0, fwd)
+        c = torch.cat([rnd.gen_c, rnd.real_c]).index_select(0, fwd) if rnd.gen_c is not None else None
+        with misc.ddp_sync(self.D, sync):
+            logits = self.D(x, c).index_select(0, inv)
+        return logits[:n], logits[n:]
 
     def _pass_d_reg(self, rnd, closes_round, reg_follows):
         if rnd.real_logits is None:          # no adversarial pass in this phase: the regularisers' shared forward on the reals (:100-105)

@@ -120,3 +120,52 @@ def test_big_gan_128_step(dev):
         eng.train_iteration(torch.rand(8, 3, 128, 128, device=dev) * 2 - 1, c)
     _finite_and_moved(eng, bg, bd)
     eng.close()
+
+
+def test_merged_discriminator_pass_equals_two_passes(dev):
+    """Dmain runs D once over [generated; real] (losses_base._pass_d_adv): the interleaved batch must give the logits and parameter gradients
+    of the two separate forwards -- in particular the minibatch-std groups must be the ones each half forms alone -- and an engine iteration
+    with the merge on must land where the two-pass iteration lands (tolerance: summation order of the weight gradients)."""
+    from style_big_gan_amd.train_parts import discriminators, losses_base
+    _, dk = _sg2_kwargs(res=32)
+    torch.manual_seed(0)
+    D = discriminators.Discriminator(**dk).to(dev)
+    assert D.batch_mergeable
+    for n in (8, 12):
+        a = torch.randn(n, 3, 32, 32, device=dev); b = torch.randn(n, 3, 32, 32, device=dev)
+        order = D.merged_batch_order(n)
+        assert order is not None and sorted(order) == list(range(2 * n))
+        fwd = torch.tensor(order, device=dev); inv = torch.empty_like(fwd); inv[fwd] = torch.arange(2 * n, device=dev)
+        la, lb = D(a, None), D(b, None)
+        (torch.nn.functional.softplus(la).mean() + torch.nn.functional.softplus(-lb).mean()).backward()
+        g_sep = [p.grad.clone() for p in D.parameters()]
+        D.zero_grad(set_to_none=True)
+        lm = D(torch.cat([a, b]).index_select(0, fwd), None).index_select(0, inv)
+        (torch.nn.functional.softplus(lm[:n]).mean() + torch.nn.functional.softplus(-lm[n:]).mean()).backward()
+        assert float((lm[:n] - la).abs().max()) <= 2e-3 * float(la.abs().max() + 1) and float((lm[n:] - lb).abs().max()) <= 2e-3 * float(lb.abs().max() + 1)
+        for gs, p in zip(g_sep, D.parameters()):
+            assert float((p.grad - gs).abs().max()) <= 2e-2 * float(gs.abs().max()) + 1e-6
+        D.zero_grad(set_to_none=True)
+    assert D.merged_batch_order(6) is None                              # groups of four do not tile six samples: the halves cannot be kept apart
+
+    gk, dk = _sg2_kwargs()
+    kw = dict(gen_kwargs=gk, disc_kwargs=dk, loss_arch_kwargs=dict(style_mixing_prob=0), dis_regs=[("r1", dict(r1_gamma=0.1))], g_reg_interval=4,
+              d_reg_interval=4, batch=8, batch_gpu=8, ema_kimg=0.05)
+    real = torch.rand(8, 3, 32, 32, device=dev) * 2 - 1
+    weights = []
+    was = losses_base.merge_d_passes
+    try:
+        for merge in (True, False):
+            losses_base.merge_d_passes = merge
+            eng = trainers.StepEngine(dev, seed=5, **kw)
+            eng.batch_idx = 1                                            # an iteration without the regulariser phases: Gmain + Dmain
+            z = torch.randn(len(eng.phases) * 8, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+            torch.manual_seed(77)
+            eng.train_iteration(real, None, all_gen_z=z)
+            weights.append([p.detach().clone() for p in eng.D.parameters()])
+    finally:
+        losses_base.merge_d_passes = was
+    lr = 0.002
+    for pa, pb in zip(*weights):      # Adam's first step moves every element by ~lr * sign(g): elements whose gradient is ~0 may differ by a full step
+        d = (pa - pb).abs()
+        assert float((d > 0.5 * lr).float().mean()) < 0.02, float((d > 0.5 * lr).float().mean())
