@@ -300,12 +300,15 @@ def main():
                 roofline['traffic_source'] = src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch averaged over the same launches)'
                 roofline['algorithmic_bytes_per_launch'] = round(kern[dom]['bytes'] / kern[dom]['launches'])
         # the 256x256 modulated 3x3 conv (M = N*65536 pixels, Cout 128, K = 9*128): the kernel the 40 % MFMA target names
+        rounds = batch // batch_gpu
+        one_pass = rounds > 1 and all(eng._rounds_in_one_pass(ph.name, rounds) for ph in eng.phases if not ph.idle)
+        pass_batch = batch if one_pass else batch_gpu          # samples per network pass
         tgt = [r for r in records if r['kind'] == 'conv_igemm' and r['dims'][1] == 128 and r['dims'][2] == 128 and r['dims'][3] == 9
-               and r['dims'][0] == batch_gpu * res * res] if args.workload == 'sg2ada' else []
+               and r['dims'][0] == pass_batch * res * res] if args.workload == 'sg2ada' else []
         target = None
         if tgt:
             fl, ms = sum(r['flops'] for r in tgt), sum(r['ms'] for r in tgt)
-            target = dict(shape=f'[{batch_gpu},128,{res},{res}] (*) [128,128,3,3]', launches=len(tgt),
+            target = dict(shape=f'[{pass_batch},128,{res},{res}] (*) [128,128,3,3]', launches=len(tgt),
                           avg_launch_ms=round(ms / len(tgt), 4), tflops=round(fl / ms / 1e9, 2), mfma_frac=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4))
         total_ms = sum(v['ms'] for v in kern.values())
         total_flops = sum(v['flops'] for v in kern.values())
@@ -331,7 +334,8 @@ def main():
             'value': round(imgs / elapsed, 2), 'unit': 'img/s',
             'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / steps * 1e3, 2),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
-            'config': {'workload': f'{wl["label"]}, global batch {global_batch} = {world} rank(s) x {batch // batch_gpu} round(s) x batch_gpu {batch_gpu}, '
+            'config': {'workload': f'{wl["label"]}, global batch {global_batch} = {world} rank(s) x {batch // batch_gpu} round(s) x batch_gpu {batch_gpu}'
+                                   + (' (the rounds of a phase evaluated in one pass, minibatch-std groups and loss those of the separate rounds), ' if one_pass else ', ')
                                    + (f'bf16 from 8x8 up (num_fp16_res {_bf16_blocks(res)}; the reference recipe defaults to 4), conv_clamp 256, ' if wl['dtype'] == 'bf16' else 'fp32 storage, ')
                                    + ('ADA off' if args.ada is None else f'ADA bgc on (p0 = {args.ada}, target 0.6; secondary measurement)'),
                        'global_batch': global_batch, 'parallelism': f'dp{world}'},

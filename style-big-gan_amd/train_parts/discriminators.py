@@ -271,22 +271,31 @@ class Discriminator(torch.nn.Module):
         # power iterations do: the attention blocks) and the minibatch-std groups are kept apart -- see merged_batch_order()
         self.batch_mergeable = len(tuple(attentions)) == 0
 
-    def merged_batch_order(self, n):
-        """index tensor (host list) that arranges cat([a, b]) (n samples each) so that the minibatch-std groups of the merged batch are exactly
-        the groups the layer forms on a and on b alone (reference MinibatchStdLayer :316-328 groups samples j, j + n/G, j + 2 n/G, ...), or
-        None when the two halves cannot be kept apart.  Position p = r + (2 n / G) k holds a[r + (n/G) k] for r < n/G, else b[r - n/G + (n/G) k]."""
+    def merged_batch_order(self, n, segments=2):
+        """index list that arranges cat([a_0, ..., a_{S-1}]) (S = `segments` batches of n samples each: the generated and the real half of a
+        round, and / or several accumulation rounds) so that the minibatch-std groups of the merged batch are exactly the groups the layer forms on
+        each a_s alone (reference MinibatchStdLayer :316-328 groups samples j, j + n/G, j + 2 n/G, ...), or None when the segments cannot be kept
+        apart.  With m = n/G groups per segment, position p = r + (S m) k holds sample (r mod m) + m k of segment r div m."""
+        S = int(segments)
         mb = self.b4.mbstd
         if mb is None:
-            return list(range(2 * n))
+            return list(range(S * n))
         G = min(int(mb.group_size), n) if mb.group_size is not None else None
-        if G is None or n % G != 0 or min(int(mb.group_size), 2 * n) != G:
+        if G is None or n % G != 0 or min(int(mb.group_size), S * n) != G:
             return None
         m = n // G
         order = []
-        for p in range(2 * n):
-            k, r = divmod(p, 2 * m)
-            order.append(r + m * k if r < m else n + (r - m) + m * k)
+        for p in range(S * n):
+            k, r = divmod(p, S * m)
+            order.append((r // m) * n + (r % m) + m * k)
         return order
+
+    def peak_activation_bytes(self):
+        """bytes per sample of the largest tensor a forward pass creates (the low-passed input of a block's strided convolution,
+        [tmp_channels, res + 1, res + 1]): what bounds the batch of one pass -- the op layer addresses tensors below 2^31 elements / 2 GiB
+        (the reference plugins' own limit, upfirdn2d.cpp:22-23)"""
+        blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
+        return max(int(b.conv1.weight.shape[1]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 4) for b in blocks)
 
     def forward(self, img, c, **block_kwargs):
         x = None

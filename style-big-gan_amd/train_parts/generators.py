@@ -270,7 +270,10 @@ class MappingNetwork(torch.nn.Module):
             w = getattr(self, f'fc{idx}')(w)
         track = self.w_avg_beta is not None and self.training and not skip_w_avg_update
         if track:
-            self.w_avg.copy_(torch.lerp(w.detach().mean(dim=0), self.w_avg, self.w_avg_beta))
+            # `w_avg_rounds` > 1 (set by StepEngine while it evaluates several accumulation rounds in one pass): the batch is [round 0; round 1; ...]
+            # and the average advances once per round, in order, exactly as it does over separate calls
+            for part in w.detach().chunk(max(int(getattr(self, 'w_avg_rounds', 1)), 1)):
+                self.w_avg.copy_(torch.lerp(part.mean(dim=0), self.w_avg, self.w_avg_beta))
         if self.num_ws is not None:
             w = w.unsqueeze(1).repeat([1, self.num_ws, 1])
         if truncation_psi == 1:
@@ -550,6 +553,15 @@ class Generator(torch.nn.Module):
         mk = dict(mapping_kwargs.items()) if mapping_kwargs is not None else {}
         mk.update(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws)
         self.mapping = MappingNetwork(**mk)
+        # several accumulation rounds may be evaluated in one pass when nothing but the mapping network's running average carries state across
+        # forward calls (the attention blocks' spectral-norm power iterations do) -- StepEngine._rounds_per_pass
+        self.rounds_mergeable = len(tuple(attentions)) == 0
+
+    def peak_activation_bytes(self):
+        """bytes per sample of the largest tensor a forward pass creates (the [C, res + 1, res + 1] output of an up-sampling convolution
+        before its low-pass); see Discriminator.peak_activation_bytes"""
+        blocks = [getattr(self.synthesis, f'b{res}') for res in self.synthesis.block_resolutions]
+        return max(int(b.conv1.weight.shape[0]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 4) for b in blocks)
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
         ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)

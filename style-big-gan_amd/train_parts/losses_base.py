@@ -18,6 +18,11 @@ Two deliberate scheduling differences, neither of which changes a parameter grad
 * discriminator regularisers differentiate D twice with respect to its input, every other phase is first order: the streaming
   fromRGB kernels (``torch_utils/ops/fromrgb.py``, first order only) are switched on for exactly those other phases.
 
+Passes may be wider than the reference's (same values, same parameter gradients up to summation order; DESIGN.md "passes per round"):
+``Dmain`` runs the discriminator once over [generated; real], and the trainer may hand several accumulation rounds to one call
+(``segments`` > 1: inputs are ``[round 0; round 1; ...]``).  Every discriminator pass over more than one such segment interleaves the samples
+so that the minibatch-std layer forms exactly the groups it forms on each segment alone (``Discriminator.merged_batch_order``).
+
 ``sync`` gates the data-parallel exchange as in the reference: only the last pass of the last accumulation round of a phase
 synchronises; the regularisers receive ``sync = (last regulariser of the list)`` (:94, :109).
 """
@@ -28,7 +33,7 @@ from ..torch_utils import misc, training_stats
 from ..torch_utils.ops import fromrgb as _fromrgb
 from ..utils import EasyDict
 from .losses import losses
-from .regularizations import discriminator_regs, generator_regs
+from .regularizations import R1reg, discriminator_regs, generator_regs
 
 losses_arch = utils.ClassRegistry()
 
@@ -37,6 +42,7 @@ _scope = torch.autograd.profiler.record_function
 import os as _os
 merge_d_passes = _os.environ.get('SBG_MERGE_D', '1') != '0'      # Dmain: one discriminator pass over [generated; real] (see _pass_d_adv)
 _order_cache = {}
+_PASS_BYTES = 1 << 31      # no tensor of a pass may reach 2 GiB (and, at two bytes per element, 2^31 elements: the op layer's limit)
 
 #             phase      passes, in execution order
 _PROGRAMS = {'Gmain': ('g_adv',), 'Greg': ('g_reg',), 'Gboth': ('g_adv', 'g_reg'),
@@ -45,11 +51,12 @@ _PROGRAMS = {'Gmain': ('g_adv',), 'Greg': ('g_reg',), 'Gboth': ('g_adv', 'g_reg'
 
 class _Round:
     """inputs of one accumulation round + what its passes hand to each other"""
-    __slots__ = ('real_img', 'real_c', 'gen_z', 'gen_c', 'sync', 'gain', 'real_logits', 'real_img_tmp')
+    __slots__ = ('real_img', 'real_c', 'gen_z', 'gen_c', 'sync', 'gain', 'real_logits', 'real_img_tmp', 'segments')
 
-    def __init__(self, real_img, real_c, gen_z, gen_c, sync, gain):
+    def __init__(self, real_img, real_c, gen_z, gen_c, sync, gain, segments=1):
         self.real_img, self.real_c, self.gen_z, self.gen_c, self.sync, self.gain = real_img, real_c, gen_z, gen_c, sync, gain
         self.real_logits = self.real_img_tmp = None
+        self.segments = segments      # accumulation rounds held by this record (inputs are [round 0; round 1; ...])
 
 
 def _report_scores(which, logits):
@@ -86,9 +93,20 @@ class LossBase:
         configured = dict(g_adv=True, d_adv=True, g_reg=self.gen_regs is not None, d_reg=self.dis_regs is not None)
         return [p for p in _PROGRAMS[phase] if configured[p]]
 
-    def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync, gain):
+    def rounds_mergeable(self, phase, n, rounds):
+        """may `rounds` accumulation rounds of `n` samples each be handed to ONE accumulate_gradients call (segments = rounds)?  Only the split
+        phases (one pass per round), only regularisers without state from round to round (R1; the path-length regulariser advances its running
+        mean per round), and only when the discriminator can keep the rounds' minibatch-std groups apart within its size limit."""
         passes = self.program(phase)
-        rnd = _Round(real_img, real_c, gen_z, gen_c, sync, gain)
+        if len(passes) != 1 or passes[0] == 'g_reg':
+            return False
+        if passes[0] == 'd_reg' and not all(type(r) is R1reg for r in self.dis_regs):
+            return False
+        return self._d_order(n, rounds, torch.device(self.device)) is not None
+
+    def accumulate_gradients(self, phase, real_img, real_c, gen_z, gen_c, sync, gain, segments=1):
+        passes = self.program(phase)
+        rnd = _Round(real_img, real_c, gen_z, gen_c, sync, gain, segments)
         first_order_d = 'd_reg' not in passes
         fromrgb_was, _fromrgb.enabled = _fromrgb.enabled, first_order_d
         try:
@@ -101,12 +119,17 @@ class LossBase:
     def _pass_g_adv(self, rnd, closes_round, reg_follows):
         """generator's adversarial loss on D(G(z)) (reference :50-61)"""
         with _scope('Gmain_forward'):
-            gen_logits = self.run_D(self.run_G(rnd.gen_z, rnd.gen_c, sync=(rnd.sync and closes_round)), rnd.gen_c, sync=False)
+            gen_img = self.run_G(rnd.gen_z, rnd.gen_c, sync=(rnd.sync and closes_round))
+            if rnd.segments > 1:
+                order = self._d_order(gen_img.shape[0] // rnd.segments, rnd.segments, gen_img.device)
+                (gen_logits,) = self._run_D_ordered([gen_img], [rnd.gen_c], order, sync=False)
+            else:
+                gen_logits = self.run_D(gen_img, rnd.gen_c, sync=False)
             _report_scores('fake', gen_logits)
-            loss_Gmain = self.loss.calc_loss(gen_logits, None)
+            loss_Gmain = self._loss_per_round(rnd.segments, gen_logits, None)
             training_stats.report('Loss/G/loss', loss_Gmain)
         with _scope('Gmain_backward'):
-            loss_Gmain.mul(rnd.gain).backward()
+            loss_Gmain.mean().mul(rnd.gain).backward()
 
     def _pass_g_reg(self, rnd, closes_round, reg_follows):
         for i, reg in enumerate(self.gen_regs):
@@ -116,65 +139,94 @@ class LossBase:
         """discriminator's loss on generated and real images; one backward covers both forwards (reference :64-81)"""
         with _scope('Dgen_forward'):
             gen_img = self.run_G(rnd.gen_z, rnd.gen_c, sync=False)          # G's parameters do not require grad in a D phase: no graph
-            order = None if reg_follows else self._merged_order(gen_img, rnd)
-            if order is not None:
-                gen_logits, rnd.real_logits = self._run_D_merged(gen_img, rnd, order, sync=(rnd.sync and closes_round))
+            n = gen_img.shape[0] // rnd.segments
+            both = None if reg_follows else self._both_halves_order(gen_img, rnd, n)
+            if both is not None:
+                gen_logits, rnd.real_logits = self._run_D_ordered([gen_img, rnd.real_img.detach()], [rnd.gen_c, rnd.real_c], both,
+                                                                  sync=(rnd.sync and closes_round))
+            elif rnd.segments > 1:
+                order = self._d_order(n, rnd.segments, gen_img.device)
+                (gen_logits,) = self._run_D_ordered([gen_img], [rnd.gen_c], order, sync=False)
+                (rnd.real_logits,) = self._run_D_ordered([rnd.real_img.detach()], [rnd.real_c], order, sync=(rnd.sync and closes_round))
             else:
                 gen_logits = self.run_D(gen_img, rnd.gen_c, sync=False)      # exchanged together with the real pass below
                 rnd.real_img_tmp = rnd.real_img.detach().requires_grad_(reg_follows)
                 rnd.real_logits = self.run_D(rnd.real_img_tmp, rnd.real_c, sync=(rnd.sync and closes_round))
             _report_scores('fake', gen_logits)
             _report_scores('real', rnd.real_logits)
-            loss_Dgen = self.loss.calc_loss(rnd.real_logits, gen_logits)
+            loss_Dgen = self._loss_per_round(rnd.segments, rnd.real_logits, gen_logits)
         with _scope('Dgen_backward'):      # a regulariser of the same phase differentiates real_logits again: keep the graph for it
             loss_Dgen.mean().mul(rnd.gain).backward(retain_graph=reg_follows)
 
-    # One discriminator pass over [generated; real] instead of two (the reference runs D twice, :66-77).  Same function values and the same
-    # parameter gradients up to summation order: the augmentation pipe still sees the two halves in the reference's order (its random draws
-    # are consumed identically), and the samples are interleaved so that the minibatch-std layer forms exactly the groups it forms on each
-    # half alone (Discriminator.merged_batch_order).  Only for a plain Dmain (no regulariser differentiating the reals in this phase) and for
-    # discriminators that declare `batch_mergeable` (no state carried across forward calls).  Worth it because the fixed cost of a pass --
-    # ~600 launches, the latency-bound 4x4 ... 32x32 layers -- is paid once: see DESIGN.md, "passes per round".
-    def _merged_order(self, gen_img, rnd):
-        if not merge_d_passes:
-            return None
+    def _loss_per_round(self, segments, pred_real, pred_fake):
+        """the loss of every accumulation round held by the logits (a scalar for one round, else [segments]): its mean times `segments` is the
+        sum over rounds the reference accumulates, and the reported statistic keeps one entry per round"""
+        if segments == 1:
+            return self.loss.calc_loss(pred_real, pred_fake)
+        fake = pred_fake.chunk(segments) if pred_fake is not None else [None] * segments
+        return torch.stack([self.loss.calc_loss(r, f) for r, f in zip(pred_real.chunk(segments), fake)])
+
+    # One discriminator pass over several batches of n samples ("segments": the generated and the real half of a round -- the reference runs D
+    # twice, :66-77 -- and / or several accumulation rounds).  Same function values and the same parameter gradients up to summation order: the
+    # augmentation pipe still sees generated images, then reals (its random draws keep that order), and the samples are interleaved so that the
+    # minibatch-std layer forms exactly the groups it forms on each segment alone (Discriminator.merged_batch_order).  Only for discriminators
+    # that declare `batch_mergeable` (no state carried across forward calls) and while no tensor of the pass reaches the op layer's 2 GiB
+    # limit.  Worth it because the fixed cost of a pass -- ~600 launches, the latency-bound 4x4 ... 32x32 layers -- is paid once: see
+    # DESIGN.md, "passes per round".
+    def _d_order(self, n, segments, device):
+        """(fwd, inv) index tensors for a pass over `segments` batches of n samples; () = natural order; None = not possible"""
+        if segments == 1:
+            return ()
         d = getattr(self.D, 'module', self.D)
-        if not getattr(d, 'batch_mergeable', False) or gen_img.shape != rnd.real_img.shape:
+        if not getattr(d, 'batch_mergeable', False):
             return None
-        if (rnd.gen_c is None) != (rnd.real_c is None) or (rnd.gen_c is not None and rnd.gen_c.shape != rnd.real_c.shape):
-            return None
-        n = gen_img.shape[0]
-        key = (id(d), n, gen_img.device)
+        key = (id(d), n, segments, device)
         hit = _order_cache.get(key)
         if hit is None:
-            order = d.merged_batch_order(n)
+            peak = d.peak_activation_bytes() if hasattr(d, 'peak_activation_bytes') else 0
+            order = d.merged_batch_order(n, segments) if segments * n * peak < _PASS_BYTES else None
             if order is None:
                 hit = (None, None)
             else:
-                fwd = torch.tensor(order, dtype=torch.int64, device=gen_img.device)
+                fwd = torch.tensor(order, dtype=torch.int64, device=device)
                 inv = torch.empty_like(fwd)
-                inv[fwd] = torch.arange(2 * n, device=gen_img.device)
+                inv[fwd] = torch.arange(segments * n, device=device)
                 hit = (fwd, inv)
             _order_cache[key] = hit
         return hit if hit[0] is not None else None
 
-    def _run_D_merged(self, gen_img, rnd, order, sync):
-        fwd, inv = order
-        n = gen_img.shape[0]
-        real = rnd.real_img.detach()
+    def _both_halves_order(self, gen_img, rnd, n):
+        """order for ONE pass over [generated; real] of a Dmain round (times the rounds held by `rnd`), or None: two passes"""
+        if not merge_d_passes or gen_img.shape != rnd.real_img.shape:
+            return None
+        if (rnd.gen_c is None) != (rnd.real_c is None) or (rnd.gen_c is not None and rnd.gen_c.shape != rnd.real_c.shape):
+            return None
+        return self._d_order(n, 2 * rnd.segments, gen_img.device)
+
+    def _run_D_ordered(self, imgs, cs, order, sync):
+        """logits of every batch in `imgs` from one discriminator pass over their concatenation arranged by `order` (see _d_order)"""
         if self.augment_pipe is not None:
-            gen_img, real = self.augment_pipe(gen_img), self.augment_pipe(real)
-        x = torch.cat([gen_img, real.to(gen_img.dtype)]).index_select(0, fwd)
-        c = torch.cat([rnd.gen_c, rnd.real_c]).index_select(0, fwd) if rnd.gen_c is not None else None
+            imgs = [self.augment_pipe(img) for img in imgs]
+        x = imgs[0] if len(imgs) == 1 else torch.cat([img.to(imgs[0].dtype) for img in imgs])
+        c = None if cs[0] is None else (cs[0] if len(cs) == 1 else torch.cat(cs))
+        if order:
+            x = x.index_select(0, order[0])
+            c = c.index_select(0, order[0]) if c is not None else None
         with misc.ddp_sync(self.D, sync):
-            logits = self.D(x, c).index_select(0, inv)
-        return logits[:n], logits[n:]
+            logits = self.D(x, c)
+        if order:
+            logits = logits.index_select(0, order[1])
+        return logits.split([img.shape[0] for img in imgs])
 
     def _pass_d_reg(self, rnd, closes_round, reg_follows):
         if rnd.real_logits is None:          # no adversarial pass in this phase: the regularisers' shared forward on the reals (:100-105)
             with _scope('Dreg_forward'):
                 rnd.real_img_tmp = rnd.real_img.detach().requires_grad_(True)
-                rnd.real_logits = self.run_D(rnd.real_img_tmp, rnd.real_c, sync=rnd.sync)
+                if rnd.segments > 1:
+                    order = self._d_order(rnd.real_img.shape[0] // rnd.segments, rnd.segments, rnd.real_img.device)
+                    (rnd.real_logits,) = self._run_D_ordered([rnd.real_img_tmp], [rnd.real_c], order, sync=rnd.sync)
+                else:
+                    rnd.real_logits = self.run_D(rnd.real_img_tmp, rnd.real_c, sync=rnd.sync)
                 _report_scores('real', rnd.real_logits)
         for i, reg in enumerate(self.dis_regs):
             reg.calc_reg(self, rnd.real_img, rnd.real_c, rnd.gen_z, rnd.gen_c, rnd.real_logits, rnd.real_img_tmp,

@@ -29,6 +29,8 @@ from .optimizers import optimizers
 
 trainers = utils.ClassRegistry()
 
+merge_rounds = os.environ.get('SBG_MERGE_ROUNDS', '1') != '0'      # accumulation rounds of a phase in one pass (StepEngine._rounds_in_one_pass)
+
 
 def lazy_reg_opt_kwargs(opt_kwargs, interval):
     """lr and betas of a phase that also carries a regulariser applied every `interval` iterations (reference :619-623)"""
@@ -60,6 +62,7 @@ class StepEngine:
         self.ema_kimg, self.ema_rampup, self.use_ema = ema_kimg, ema_rampup, use_ema
         self.cur_nimg = 0
         self.batch_idx = 0
+        self._round_plan = {}
 
         torch.manual_seed(seed * max(world_size, 1) + rank)     # reference :507-508
         self.G = generators[generator](**(gen_kwargs or {})).train().requires_grad_(False).to(self.device)
@@ -167,9 +170,21 @@ class StepEngine:
                 for r in phase.reducers:
                     r.zero_grad()
                 phase.module.requires_grad_(True)
-                for round_idx, (img, c, z, gc) in enumerate(zip(reals, real_cs, phase_z, phase_c)):
-                    sync = (round_idx == rounds - 1)
-                    self.loss.accumulate_gradients(phase=phase.name, real_img=img, real_c=c, gen_z=z, gen_c=gc, sync=sync, gain=phase.interval)
+                if self._rounds_in_one_pass(phase.name, rounds):
+                    # every loss term is a mean over the pass: the mean over `rounds` rounds times `rounds` is the sum of the rounds' means
+                    mapping = getattr(self.G, 'mapping', None)
+                    if mapping is not None:
+                        mapping.w_avg_rounds = rounds
+                    try:
+                        self.loss.accumulate_gradients(phase=phase.name, real_img=real_img, real_c=torch.cat(real_cs), gen_z=torch.cat(phase_z),
+                                                       gen_c=torch.cat(phase_c), sync=True, gain=phase.interval * rounds, segments=rounds)
+                    finally:
+                        if mapping is not None:
+                            mapping.w_avg_rounds = 1
+                else:
+                    for round_idx, (img, c, z, gc) in enumerate(zip(reals, real_cs, phase_z, phase_c)):
+                        sync = (round_idx == rounds - 1)
+                        self.loss.accumulate_gradients(phase=phase.name, real_img=img, real_c=c, gen_z=z, gen_c=gc, sync=sync, gain=phase.interval)
                 phase.module.requires_grad_(False)
             with torch.autograd.profiler.record_function(phase.name + '_opt'):
                 for r in phase.reducers:
@@ -200,6 +215,24 @@ class StepEngine:
                 # the sampler keeps the old strength for exactly one more iteration, then switches (deterministic, identical on all ranks)
                 self.augment_pipe.announce_strength_update()
                 self._ada_adopt_at = self.batch_idx + 1
+
+    def _rounds_in_one_pass(self, phase_name, rounds):
+        """The accumulation rounds of a phase exist in the reference because a round is what fits its device (`batch_gpu`); here 288 GB hold
+        them all, and every network pass carries ~1 ms of fixed cost ("passes per round").  The rounds of a phase are therefore
+        evaluated in ONE pass over [round 0; round 1; ...] when that computes the same thing: per-sample-independent networks (StyleGAN2 blocks
+        without attention: no batch statistics, no power iterations), the mapping network's running average advanced once per round in order
+        (MappingNetwork.w_avg_rounds), minibatch-std groups kept those of the separate rounds (Discriminator.merged_batch_order), stateless
+        regularisers, and no tensor of the pass at the op layer's 2 GiB limit.  Same losses, statistics and parameter gradients up to
+        summation order; the per-layer noise and the augmentation pipe draw once for the whole pass instead of once per round (same
+        distribution).  SBG_MERGE_ROUNDS=0 keeps the rounds apart."""
+        if rounds <= 1 or not merge_rounds or not getattr(self.G, 'rounds_mergeable', False):
+            return False
+        hit = self._round_plan.get((phase_name, rounds))
+        if hit is None:
+            peak = self.G.peak_activation_bytes() if hasattr(self.G, 'peak_activation_bytes') else 0
+            hit = rounds * self.batch_gpu * peak < (1 << 31) and self.loss.rounds_mergeable(phase_name, self.batch_gpu, rounds)
+            self._round_plan[(phase_name, rounds)] = hit
+        return hit
 
     # -- snapshot / resume (reference trainers.py:636-656 pickles whole modules; here plain state dicts + counters) ---------
     def state_dict(self):

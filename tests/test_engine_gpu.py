@@ -169,3 +169,69 @@ def test_merged_discriminator_pass_equals_two_passes(dev):
     for pa, pb in zip(*weights):      # Adam's first step moves every element by ~lr * sign(g): elements whose gradient is ~0 may differ by a full step
         d = (pa - pb).abs()
         assert float((d > 0.5 * lr).float().mean()) < 0.02, float((d > 0.5 * lr).float().mean())
+
+
+def test_rounds_in_one_pass_equal_separate_rounds(dev):
+    """StepEngine evaluates the accumulation rounds of a split phase in ONE pass over [round 0; round 1; ...] (StepEngine._rounds_in_one_pass):
+    the discriminator must form the minibatch-std groups of the separate rounds for any number of segments, and an iteration (Gmain, Dmain,
+    Dreg with R1) must land where the round-by-round iteration lands, including the mapping network's running average, which advances once
+    per round.  (The reference's own two-round schedule is met by tests/test_reference_vectors_gpu.py::test_step_engine_against_reference_schedule,
+    whose r1 fixture has batch 4 = 2 x batch_gpu 2 and runs through this path.)"""
+    from style_big_gan_amd.train_parts import discriminators, generators
+    gk, dk = _sg2_kwargs(res=32)
+    torch.manual_seed(0)
+    D = discriminators.Discriminator(**dk).to(dev)
+    n = 8
+    for S in (3, 4):
+        parts = [torch.randn(n, 3, 32, 32, device=dev) for _ in range(S)]
+        order = D.merged_batch_order(n, S)
+        assert order is not None and sorted(order) == list(range(S * n))
+        fwd = torch.tensor(order, device=dev); inv = torch.empty_like(fwd); inv[fwd] = torch.arange(S * n, device=dev)
+        with torch.no_grad():
+            sep = torch.cat([D(x, None) for x in parts])
+            one = D(torch.cat(parts).index_select(0, fwd), None).index_select(0, inv)
+        assert float((one - sep).abs().max()) <= 2e-3 * float(sep.abs().max() + 1)
+    assert D.merged_batch_order(6, 3) is None
+    assert D.peak_activation_bytes() == 32 * 33 * 33 * 2 and generators.Generator(**gk).peak_activation_bytes() == 32 * 33 * 33 * 2
+
+    real = torch.rand(16, 3, 32, 32, device=dev) * 2 - 1
+    was = trainers.merge_rounds
+    # fp32 networks: the two schedules are the same sums in another order (2e-4 of each tensor's largest gradient); bf16 from 4x4 up: the
+    # reorderings also move roundings of the 16-bit activations of two networks in a row
+    for nfp, tol in ((0, 2e-4), (8, 5e-2)):
+        gk, dk = _sg2_kwargs(res=32, nfp=nfp)
+        kw = dict(gen_kwargs=gk, disc_kwargs=dk, loss_arch_kwargs=dict(style_mixing_prob=0), dis_regs=[("r1", dict(r1_gamma=0.1))], g_reg_interval=4,
+                  d_reg_interval=4, batch=16, batch_gpu=8, ema_kimg=0.05)
+        out = []
+        try:
+            for merge in (True, False):
+                trainers.merge_rounds = merge
+                eng = trainers.StepEngine(dev, seed=5, **kw)
+                for m in eng.G.synthesis.modules():                      # the per-layer noise is drawn per pass: one draw of 16 vs two of 8
+                    if hasattr(m, 'use_noise'):
+                        m.use_noise = False
+                assert [eng._rounds_in_one_pass(p.name, 2) for p in eng.phases] == [merge, False, merge, merge]      # Gmain, (idle) Greg, Dmain, Dreg
+                z = torch.randn(len(eng.phases) * 16, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+                grads = {}
+                for ph in eng.phases:                                    # the gradients each phase hands to its optimizer step
+                    def step(ph=ph, inner=ph.opt.step):
+                        grads[ph.name] = [p.grad.detach().clone() for p in ph.module.parameters() if p.grad is not None]
+                        return inner()
+                    ph.opt.step = step
+                eng.train_iteration(real, None, all_gen_z=z)             # iteration 0: every phase runs
+                out.append((grads, eng.G.mapping.w_avg.clone()))
+                eng.close()
+        finally:
+            trainers.merge_rounds = was
+        (ga, avg_a), (gb, avg_b) = out
+        assert float((avg_a - avg_b).abs().max()) <= 1e-5 * float(avg_b.abs().max() + 1e-3)
+        assert set(ga) == set(gb) >= {'Gmain', 'Dmain', 'Dreg'}     # (main and lazy-regulariser slots share an optimizer: a step records under both names)
+        for name in gb:
+            assert len(ga[name]) == len(gb[name]) > 0
+            for a, b in zip(ga[name], gb[name]):
+                assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-7, (nfp, name, tuple(b.shape), float((a - b).abs().max()), float(b.abs().max()))
+
+    gk2, dk2 = _sg2_kwargs(res=32, attn_g=(16,))                         # power iterations in G's attention block: rounds stay apart
+    eng = trainers.StepEngine(dev, seed=5, gen_kwargs=gk2, disc_kwargs=dk2, loss_arch_kwargs=dict(style_mixing_prob=0), batch=16, batch_gpu=8)
+    assert not any(eng._rounds_in_one_pass(p.name, 2) for p in eng.phases)
+    eng.close()
