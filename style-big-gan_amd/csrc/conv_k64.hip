@@ -50,49 +50,70 @@ template <int TC, int TP, int YDT, bool PLAIN, bool NUNI, class PixFn>
 static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix, int64_t ybase)
 {
     // NUNI: every pixel of the wave lies in one image (halo kernel), so the demodulation coefficients are per-h constants.
+    // Every parameter load (noise per pixel, bias and demodulation coefficients per channel group) is issued up front and UNCONDITIONALLY -- an
+    // absent term reads a valid dummy address (the first 16 bytes of x) and is replaced by a select -- so the wave waits for ONE round trip.
+    // (With `if (p.noise) nz = p.noise[...]` per pixel the compiler emitted load, s_waitcnt vmcnt(0), branch join four times over, plus two
+    // more waits for bias and coefficients: six exposed L2 / HBM latencies per tile, more than the arithmetic.)
     constexpr int TH2 = TC / 2;
     const float alpha = (p.act == SBG_ACT_LRELU) ? p.alpha : (p.act == SBG_ACT_RELU ? 0.f : 1.f);
+    const float lsel = alpha <= 1.f ? __builtin_inff() : -__builtin_inff();      // leaky ReLU = med3(u, alpha u, +inf) = max for alpha <= 1, min (-inf) above
     const float cl = p.clamp >= 0.f ? p.clamp : __builtin_inff();
     const float gain = p.gain;
+    const float* const dummy = reinterpret_cast<const float*>(p.x);
+    const bool has_nz = !PLAIN && p.noise != nullptr, has_b = !PLAIN && p.bias != nullptr, has_s = !PLAIN && p.oscale != nullptr;
     int64_t yoff[TP]; float nz[TP]; bool ok[TP]; int nn[TP];
 #pragma unroll
     for (int j = 0; j < TP; j++) {
         int n, oy, ox;
-        ok[j] = pix(j, n, oy, ox);
+        ok[j] = pix(j, n, oy, ox);                      // (an out-of-range pixel still decodes to valid coordinates)
         nn[j] = n;
         yoff[j] = ybase + (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
         nz[j] = 0.f;
-        if (!PLAIN && p.noise && ok[j]) nz[j] = p.noise[(int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox];
+        if (!PLAIN) nz[j] = *(has_nz ? p.noise + ((int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox) : dummy);
+    }
+    float4_t b_lo[TH2], b_hi[TH2], s_lo[TH2], s_hi[TH2];
+#pragma unroll
+    for (int h = 0; h < TH2; h++) {
+        b_lo[h] = b_hi[h] = float4_t{0.f, 0.f, 0.f, 0.f};
+        s_lo[h] = s_hi[h] = float4_t{1.f, 1.f, 1.f, 1.f};
+        if (!PLAIN) {
+            const float* b = has_b ? p.bias + cbase + 32 * h + 8 * fg : dummy;
+            b_lo[h] = *reinterpret_cast<const float4_t*>(b); b_hi[h] = *reinterpret_cast<const float4_t*>(has_b ? b + 4 : dummy);
+            if (NUNI) {
+                const float* sc = has_s ? p.oscale + (int64_t)nn[0] * p.Cout + cbase + 32 * h + 8 * fg : dummy;
+                s_lo[h] = *reinterpret_cast<const float4_t*>(sc); s_hi[h] = *reinterpret_cast<const float4_t*>(has_s ? sc + 4 : dummy);
+            }
+        }
+    }
+    if (!PLAIN) {
+#pragma unroll
+        for (int j = 0; j < TP; j++) nz[j] = has_nz ? nz[j] : 0.f;
+#pragma unroll
+        for (int h = 0; h < TH2; h++) {
+            if (!has_b) { b_lo[h] = float4_t{0.f, 0.f, 0.f, 0.f}; b_hi[h] = b_lo[h]; }
+            if (!NUNI || !has_s) { s_lo[h] = float4_t{1.f, 1.f, 1.f, 1.f}; s_hi[h] = s_lo[h]; }
+        }
     }
 #pragma unroll
     for (int h = 0; h < TH2; h++) {
-        float4_t b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo, s_lo = {1.f, 1.f, 1.f, 1.f}, s_hi = s_lo;
-        if (!PLAIN) {
-            if (p.bias) {
-                const float* b = p.bias + cbase + 32 * h + 8 * fg;
-                b_lo = *reinterpret_cast<const float4_t*>(b); b_hi = *reinterpret_cast<const float4_t*>(b + 4);
-            }
-            if (NUNI && p.oscale) {
-                const float* sc = p.oscale + (int64_t)nn[0] * p.Cout + cbase + 32 * h + 8 * fg;
-                s_lo = *reinterpret_cast<const float4_t*>(sc); s_hi = *reinterpret_cast<const float4_t*>(sc + 4);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < TP; j++) {
             if (!ok[j]) continue;
             float4_t lo = acc[2 * h][j], hi = acc[2 * h + 1][j];
             if (!PLAIN) {
-                if (!NUNI && p.oscale) {
+                float4_t sl = s_lo[h], sh = s_hi[h];
+                if (!NUNI && has_s) {
                     const float* sc = p.oscale + (int64_t)nn[j] * p.Cout + cbase + 32 * h + 8 * fg;
-                    s_lo = *reinterpret_cast<const float4_t*>(sc); s_hi = *reinterpret_cast<const float4_t*>(sc + 4);
+                    sl = *reinterpret_cast<const float4_t*>(sc); sh = *reinterpret_cast<const float4_t*>(sc + 4);
                 }
-                lo = lo * s_lo + (nz[j] + b_lo);
-                hi = hi * s_hi + (nz[j] + b_hi);
+                lo = lo * sl + (nz[j] + b_lo[h]);
+                hi = hi * sh + (nz[j] + b_hi[h]);
+                const float4_t tl = lo * alpha, th = hi * alpha;       // vector forms: v_pk_mul_f32
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float u = lo[e]; u = (u > 0.f) ? u : u * alpha; lo[e] = __builtin_amdgcn_fmed3f(u * gain, -cl, cl);
-                    float w = hi[e]; w = (w > 0.f) ? w : w * alpha; hi[e] = __builtin_amdgcn_fmed3f(w * gain, -cl, cl);
-                }
+                for (int e = 0; e < 4; e++) { lo[e] = __builtin_amdgcn_fmed3f(lo[e], tl[e], lsel); hi[e] = __builtin_amdgcn_fmed3f(hi[e], th[e], lsel); }
+                lo = lo * gain; hi = hi * gain;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { lo[e] = __builtin_amdgcn_fmed3f(lo[e], -cl, cl); hi[e] = __builtin_amdgcn_fmed3f(hi[e], -cl, cl); }
             }
             if (YDT == SBG_F32) {
                 float* dst = (float*)p.y + yoff[j] + 32 * h;
