@@ -61,13 +61,13 @@ def sg2ada_kwargs(res=RES, num_fp16_res=None, conv_clamp=256, channel_base=32768
     return gk, dk
 
 
-def workload(name, res=None):
+def workload(name, res=None, nfp=None):
     """-> dict(res, batch, batch_gpu, c_dim, dtype, label, steps (default K), engine (StepEngine keywords))"""
     sg2 = dict(generator='sg2_classic', discriminator='sg2_classic', loss_arch='sg2', loss='softplus', loss_arch_kwargs=dict(style_mixing_prob=0),
                optim_gen=('adam', dict(ADAM)), optim_disc=('adam', dict(ADAM)))
     if name == 'sg2ada':
         res = res or 256
-        gk, dk = sg2ada_kwargs(res=res)
+        gk, dk = sg2ada_kwargs(res=res, num_fp16_res=nfp)
         return dict(res=res, batch=64, batch_gpu=32, c_dim=0, dtype='bf16', steps=8,
                     label=f'configs/sg2ada.yaml @ {res}x{res}: sg2_classic G (skip) + D (orig), softplus + R1(0.01)/4, idle Greg slot /16 (G lr x 16/17)',
                     engine=dict(sg2, gen_kwargs=gk, disc_kwargs=dk, gen_regs=[], dis_regs=[('r1', dict(r1_gamma=0.01))], g_reg_interval=16,
@@ -197,6 +197,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-rank batch (weak) / global batch (strong); default: the config\'s')
     ap.add_argument('--batch-gpu', type=int, default=None)
     ap.add_argument('--ada', type=float, default=None, metavar='P', help="secondary measurement: 'bgc' ADA pipe on, starting strength P (headline = off)")
+    ap.add_argument('--num-fp16-res', type=int, default=None, metavar='K',
+                    help='secondary measurement: reduced precision in the K highest resolutions only (the reference recipe: 4; 0 = fp32 storage everywhere)')
     ap.add_argument('--kernel-breakdown', action='store_true', help='print the per-kernel launch log summary to stderr')
     ap.add_argument('--single-thread-autograd', action='store_true',
                     help='run backward on the calling thread (profiling under rocprofv3 counter collection: see DESIGN.md, "queue interception")')
@@ -219,7 +221,8 @@ def main():
 
     if args.single_thread_autograd:
         torch.autograd.set_multithreading_enabled(False)
-    wl = workload(args.workload, args.res)
+    assert args.num_fp16_res is None or args.workload == 'sg2ada', '--num-fp16-res: headline workload only'
+    wl = workload(args.workload, args.res, args.num_fp16_res)
     res = wl['res']
     steps = args.steps if args.steps is not None else wl['steps']
     cfg_batch = args.batch or wl['batch']
@@ -329,14 +332,18 @@ def main():
             cpu = cpu_baseline(res=res)
         imgs = steps * global_batch
         headline = args.workload == 'sg2ada'
+        if args.num_fp16_res == 0:
+            wl['dtype'] = 'f32'          # fp32 storage everywhere (convolutions as split-bf16 MFMA products, fp32 accumulate)
         out = {
-            'metric': 'images/sec (G+D step) StyleGAN2-ADA 256x256 bf16' if headline and res == 256 else f'images/sec (G+D step) {args.workload} {res}x{res} {wl["dtype"]}',
+            'metric': 'images/sec (G+D step) StyleGAN2-ADA 256x256 bf16' if headline and res == 256 and wl['dtype'] == 'bf16' else f'images/sec (G+D step) {args.workload} {res}x{res} {wl["dtype"]}',
             'value': round(imgs / elapsed, 2), 'unit': 'img/s',
             'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / steps * 1e3, 2),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
             'config': {'workload': f'{wl["label"]}, global batch {global_batch} = {world} rank(s) x {batch // batch_gpu} round(s) x batch_gpu {batch_gpu}'
                                    + (' (the rounds of a phase evaluated in one pass, minibatch-std groups and loss those of the separate rounds), ' if one_pass else ', ')
-                                   + (f'bf16 from 8x8 up (num_fp16_res {_bf16_blocks(res)}; the reference recipe defaults to 4), conv_clamp 256, ' if wl['dtype'] == 'bf16' else 'fp32 storage, ')
+                                   + ((f'bf16 from 8x8 up (num_fp16_res {_bf16_blocks(res)}; the reference recipe defaults to 4), conv_clamp 256, ' if args.num_fp16_res is None else
+                                       f'bf16 in the {args.num_fp16_res} highest resolutions (num_fp16_res {args.num_fp16_res}; secondary measurement), fp32 storage below, conv_clamp 256, ')
+                                      if wl['dtype'] == 'bf16' else 'fp32 storage, ')
                                    + ('ADA off' if args.ada is None else f'ADA bgc on (p0 = {args.ada}, target 0.6; secondary measurement)'),
                        'global_batch': global_batch, 'parallelism': f'dp{world}'},
             'roofline': roofline, 'target_kernel': target, 'cpu_baseline': cpu,

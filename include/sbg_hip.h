@@ -185,6 +185,12 @@ int sbg_scale_shift_nc(const void* x, const float* a, const float* b, void* y, i
 int sbg_dot_hw_splits(int layout, int N, int C, int64_t HW);
 int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layout,
                int N, int C, int64_t HW, sbg_stream_t stream);
+/* Both gradients of y = x * a[n, c] (the style modulation in front of a convolution, train_parts/generators.py:79; autograd's
+ * `dy * a` and `(dy * x).sum([2, 3])`) in ONE pass over u = dy and v = x, channel-minor tensors with C / 8 dividing 256:
+ *   y[n,p,c] = u[n,p,c] * scale[n*C + c]     and     partial[s][n*C + c] as sbg_dot_hw(u, v). */
+int sbg_dot_hw_scale_supported(int C);
+int sbg_dot_hw_scale(const void* u, const void* v, const float* scale, void* y, float* partial, int dtype,
+                     int N, int C, int64_t HW, sbg_stream_t stream);
 
 
 /* Backward head of the fused modulated-convolution layer (train_parts/generators.py:79-88 + :328, i.e. modulated_conv2d's

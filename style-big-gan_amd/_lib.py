@@ -126,6 +126,8 @@ SYMBOLS = [
     ("sbg_attention_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_dot_hw_splits", _c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64]),
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
+    ("sbg_dot_hw_scale_supported", _c.c_int, [_c.c_int]),
+    ("sbg_dot_hw_scale", _c.c_int, [_c.c_void_p] * 5 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_modconv_bwd_supported", _c.c_int, [_c.c_int]),
     ("sbg_modconv_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
     ("sbg_pack_weight", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int] + [_c.c_int64] * 4

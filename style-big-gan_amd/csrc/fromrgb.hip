@@ -87,11 +87,15 @@ __global__ void __launch_bounds__(256) fromrgb_fwd_kernel(FromArgs p)
     }
 }
 
-template <class T>
+// CI = image channels the lane arithmetic is unrolled for (3: RGB, the case that carries the bytes; MAX_CI: any);  DIMG = the image gradient
+// is wanted (generator phases) -- without it the per-pixel products with w and the cross-lane sums disappear from the loop.
+template <class T, int CI, bool DIMG>
 __global__ void __launch_bounds__(256) fromrgb_bwd_kernel(FromArgs p)
 {
+    constexpr int RS = MAX_CI * 8 + 8 + 1;                 // floats per (wave, channel lane) row of the final reduction
     __shared__ float4_t px[256];
-    __shared__ float red[4][64][MAX_CI * 8 + 8 + 1];
+    extern __shared__ float red[];                        // [4 waves][lpp channel lanes][RS]: 10.5 KB at 128 channels, so LDS does not cap the
+                                                          // occupancy of a streaming kernel (a [4][64][RS] array did: three workgroups per CU)
     const int lpp = p.Co >> 3, ppw = 64 / lpp;
     const int n = blockIdx.x / p.blocks_per_n, blk = blockIdx.x % p.blocks_per_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,7 +118,10 @@ __global__ void __launch_bounds__(256) fromrgb_bwd_kernel(FromArgs p)
     const float* ib = p.img + (int64_t)n * p.Ci * p.HW;
     const T* dyb = (const T*)p.dy + (int64_t)n * p.HW * p.Co;
     const T* ysb = (const T*)p.ysaved + (int64_t)n * p.HW * p.Co;
-    float* dib = p.dimg ? p.dimg + (int64_t)n * p.Ci * p.HW : nullptr;
+    float* dib = DIMG ? p.dimg + (int64_t)n * p.Ci * p.HW : nullptr;
+    // slope of clamp(act(x) * gain) on either side of zero (piecewise linear activations; bias_act.cu:141 conventions), zero on the rails
+    const float gpos = p.gain, gneg = p.act == SBG_ACT_LRELU ? p.gain * p.alpha : (p.act == SBG_ACT_RELU ? 0.0f : p.gain);
+    const float rail = p.clamp >= 0.0f ? clamp_r : __builtin_inff();
     for (int64_t chunk = (int64_t)blk * 256; chunk < p.HW; chunk += (int64_t)p.blocks_per_n * 256) {
         {
             const int64_t pix = chunk + threadIdx.x;
@@ -141,14 +148,15 @@ __global__ void __launch_bounds__(256) fromrgb_bwd_kernel(FromArgs p)
             float di[MAX_CI] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float d1 = ok ? g[j] * act_grad_from_y(yv[j], p.act, p.alpha, p.gain, clamp_r) : 0.0f;
+                const bool live = ok && (fabsf(yv[j]) < rail);
+                const float d1 = live ? g[j] * (yv[j] > 0.0f ? gpos : gneg) : 0.0f;
                 db[j] += d1;
 #pragma unroll
-                for (int c = 0; c < MAX_CI; c++) { dw[c][j] += d1 * v[c]; di[c] += d1 * w[c][j]; }
+                for (int c = 0; c < CI; c++) { dw[c][j] += d1 * v[c]; if (DIMG) di[c] += d1 * w[c][j]; }
             }
-            if (dib) {          // sum over the pixel's lanes (every lane ends with the total), then lane c mod lpp writes channel c
+            if (DIMG) {         // sum over the pixel's lanes (every lane ends with the total), then lane c mod lpp writes channel c
 #pragma unroll
-                for (int c = 0; c < MAX_CI; c++) {
+                for (int c = 0; c < CI; c++) {
                     float a = di[c];
                     for (int m = lpp >> 1; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
                     if (ok && cl == (c & (lpp - 1)) && c < p.Ci) dib[(int64_t)c * p.HW + pix] = a;
@@ -156,12 +164,18 @@ __global__ void __launch_bounds__(256) fromrgb_bwd_kernel(FromArgs p)
             }
         }
     }
-    // fixed-order block reduction of dw / db over the pixel groups and the four waves
+    // fixed-order reduction of dw / db: over the wave's pixel groups by a butterfly (lanes cl, cl + lpp, ...), then over the four waves
 #pragma unroll
     for (int j = 0; j < 8; j++) {
 #pragma unroll
-        for (int c = 0; c < MAX_CI; c++) red[wave][lane][c * 8 + j] = dw[c][j];
-        red[wave][lane][MAX_CI * 8 + j] = db[j];
+        for (int c = 0; c < MAX_CI; c++) {
+            float a = c < CI ? dw[c][j] : 0.0f;
+            for (int m = lpp; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+            if (pl == 0) red[(wave * lpp + cl) * RS + c * 8 + j] = a;
+        }
+        float a = db[j];
+        for (int m = lpp; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+        if (pl == 0) red[(wave * lpp + cl) * RS + MAX_CI * 8 + j] = a;
     }
     __syncthreads();
     // partial layout: [N][blocks_per_n][Co * Ci + Co]
@@ -172,8 +186,7 @@ __global__ void __launch_bounds__(256) fromrgb_bwd_kernel(FromArgs p)
         const int gq = co >> 3, j = co & 7;
         const int slot = is_b ? MAX_CI * 8 + j : c * 8 + j;
         float s = 0.0f;
-        for (int wv = 0; wv < 4; wv++)
-            for (int q = 0; q < ppw; q++) s += red[wv][q * lpp + gq][slot];
+        for (int wv = 0; wv < 4; wv++) s += red[(wv * lpp + gq) * RS + slot];
         out[idx] = s;
     }
 }
@@ -240,8 +253,12 @@ extern "C" int sbg_fromrgb_bwd(const float* img, const float* w, const void* dy,
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_FROMRGB, 4.0 * N * Co * (double)Ci * HW, (double)N * HW * (4.0 * Co + 8.0 * Ci), {N, Ci, Co, (int)HW, 1, 0, 0});
     dim3 grid((unsigned)(N * a.blocks_per_n)), block(256);
-    if (dtype == SBG_BF16) SBG_LAUNCH(fromrgb_bwd_kernel<bf16_s>, grid, block, 0, stream, a);
-    else                   SBG_LAUNCH(fromrgb_bwd_kernel<f16_s>, grid, block, 0, stream, a);
+    const int lds = 4 * (Co >> 3) * (MAX_CI * 8 + 8 + 1) * (int)sizeof(float);      // <= 42 KB (Co = 512)
+#define SBG_FROMRGB_BWD(T_) do { \
+        if (Ci == 3) { if (dimg) SBG_LAUNCH((fromrgb_bwd_kernel<T_, 3, true>), grid, block, lds, stream, a); else SBG_LAUNCH((fromrgb_bwd_kernel<T_, 3, false>), grid, block, lds, stream, a); } \
+        else { if (dimg) SBG_LAUNCH((fromrgb_bwd_kernel<T_, MAX_CI, true>), grid, block, lds, stream, a); else SBG_LAUNCH((fromrgb_bwd_kernel<T_, MAX_CI, false>), grid, block, lds, stream, a); } } while (0)
+    if (dtype == SBG_BF16) SBG_FROMRGB_BWD(bf16_s); else SBG_FROMRGB_BWD(f16_s);
+#undef SBG_FROMRGB_BWD
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }

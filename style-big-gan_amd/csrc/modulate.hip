@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void scale_nc_scalar(ScaleArgs p, int layout)
 }
 
 // ---- dot_hw ---------------------------------------------------------------------------------------------------------
-struct DotArgs { const void* u; const void* v; float* partial; int N, C; int64_t HW; int nsplit; int64_t pix_per_split; };
+struct DotArgs { const void* u; const void* v; float* partial; int N, C; int64_t HW; int nsplit; int64_t pix_per_split;
+                 const float* scale; void* y; };      // optional second result of the same pass: y = u * scale[n, c]  (sbg_dot_hw_scale)
 
 #define DOT_PIX_PER_SPLIT 2048
 
@@ -73,9 +74,11 @@ __global__ __launch_bounds__(256) void dot_hw_cminor8(DotArgs p)
     // stride the split; other channel counts walk whole channel vectors serially.
     if (cv <= 256 && (256 % cv) == 0) {
         const int myc = threadIdx.x % cv, plane = threadIdx.x / cv, planes = 256 / cv;
-        float acc[8];
+        float acc[8], sc[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = 0.f;
+        for (int j = 0; j < 8; j++) { acc[j] = 0.f; sc[j] = 0.f; }
+        T* py = (T*)p.y;
+        if (py) Vec8<float>::ld(p.scale + (int64_t)n * p.C + (myc << 3), sc);
         for (int64_t pix = p0 + plane; pix < p1; pix += planes) {
             float a[8], b[8];
             const int64_t off = base + pix * p.C + (myc << 3);
@@ -86,6 +89,11 @@ __global__ __launch_bounds__(256) void dot_hw_cminor8(DotArgs p)
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; j++) acc[j] += a[j];
+            }
+            if (py) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] *= sc[j];
+                Vec8<T>::st(py + off, a);
             }
         }
 #pragma unroll
@@ -318,7 +326,7 @@ extern "C" int sbg_dot_hw(const void* u, const void* v, float* partial, int dtyp
     SBG_CHECK(layout == 0 || layout == 1, "dot_hw: layout must be 0 (planar) or 1 (channel-minor)");
     SBG_CHECK(N >= 1 && C >= 1 && HW >= 1, "dot_hw: bad sizes");
     SBG_CHECK((int64_t)N * C <= INT32_MAX, "dot_hw: too many (sample, channel) pairs");
-    DotArgs p; p.u = u; p.v = v; p.partial = partial; p.N = N; p.C = C; p.HW = HW;
+    DotArgs p; p.u = u; p.v = v; p.partial = partial; p.N = N; p.C = C; p.HW = HW; p.scale = nullptr; p.y = nullptr;
     const bool fast = dot_fast(layout, C) && sbg_aligned16(u) && (!v || sbg_aligned16(v));
     p.nsplit = dot_fast(layout, C) ? sbg_dot_hw_splits(layout, N, C, HW) : 1;
     p.pix_per_split = (HW + p.nsplit - 1) / p.nsplit;
@@ -332,6 +340,34 @@ extern "C" int sbg_dot_hw(const void* u, const void* v, float* partial, int dtyp
     return run_dot<bf16_s>(p, layout, fast, s);
 }
 
+
+// One pass over (u, v) for both gradients of y = x * a[n, c] given u = dy, v = x:  partial sums of u * v (-> da) AND dx = u * scale.
+extern "C" int sbg_dot_hw_scale_supported(int C)
+{
+    const int cv = C >> 3;
+    return (C % 8) == 0 && cv >= 1 && cv <= 256 && (256 % cv) == 0;       // the lane-owns-a-channel-vector form of dot_hw_cminor8
+}
+
+extern "C" int sbg_dot_hw_scale(const void* u, const void* v, const float* scale, void* y, float* partial, int dtype,
+                                int N, int C, int64_t HW, sbg_stream_t stream)
+{
+    SBG_CHECK(u && v && scale && y && partial, "dot_hw_scale: null pointer");
+    SBG_CHECK(dtype == SBG_F32 || dtype == SBG_F16 || dtype == SBG_BF16, "dot_hw_scale: unsupported dtype %d", dtype);
+    SBG_CHECK(N >= 1 && HW >= 1 && sbg_dot_hw_scale_supported(C) && dot_fast(1, C), "dot_hw_scale: channel-minor tensors with C / 8 dividing 256 (got C = %d)", C);
+    SBG_CHECK((int64_t)N * C <= INT32_MAX, "dot_hw_scale: too many (sample, channel) pairs");
+    SBG_CHECK(sbg_aligned16(u) && sbg_aligned16(v) && sbg_aligned16(y) && sbg_aligned16(scale), "dot_hw_scale: tensors must be 16-byte aligned");
+    DotArgs p; p.u = u; p.v = v; p.partial = partial; p.N = N; p.C = C; p.HW = HW; p.scale = scale; p.y = y;
+    p.nsplit = sbg_dot_hw_splits(1, N, C, HW);
+    p.pix_per_split = (HW + p.nsplit - 1) / p.nsplit;
+    hipStream_t s = (hipStream_t)stream;
+    const double es = dtype == SBG_F32 ? 4 : 2;
+    SbgProfScope prof(s, SBG_K_DOT_HW, 0.0, 3.0 * es * N * (double)C * HW, {N, C, (int)HW, 3});
+    if (dtype == SBG_F32)      SBG_LAUNCH((dot_hw_cminor8<float>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    else if (dtype == SBG_F16) SBG_LAUNCH((dot_hw_cminor8<f16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    else                       SBG_LAUNCH((dot_hw_cminor8<bf16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
 
 extern "C" int sbg_modconv_bwd_supported(int C)
 {

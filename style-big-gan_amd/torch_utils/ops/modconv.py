@@ -78,10 +78,14 @@ class _ModConvBiasAct(torch.autograd.Function):
         ccfg = (False, (1, 1), (padding, padding), (0, 0))
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             dxs = _cg._Conv.apply(d2, w, (True, (1, 1), (padding, padding), (0, 0)))
-            if ctx.needs_input_grad[0]:
-                dx = _mod._scale_nc_launch(dxs, styles, None)
-            if ctx.needs_input_grad[2]:
-                dstyles = _mod._dot_hw_launch(dxs, x).to(styles.dtype).reshape(styles.shape)
+            both = _mod._dot_hw_scale_launch(dxs, x, styles) if (ctx.needs_input_grad[0] and ctx.needs_input_grad[2]) else None
+            if both is not None:                             # dx = dxs * s and sum_hw dxs * x from one pass over (dxs, x)
+                dx, dstyles = both[0], both[1].to(styles.dtype).reshape(styles.shape)
+            else:
+                if ctx.needs_input_grad[0]:
+                    dx = _mod._scale_nc_launch(dxs, styles, None)
+                if ctx.needs_input_grad[2]:
+                    dstyles = _mod._dot_hw_launch(dxs, x).to(styles.dtype).reshape(styles.shape)
         if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
             dw = _cg._ConvWgrad.apply(d2, xs, ccfg, tuple(w.shape), _cg.wmeta_of(xs, w))
         return dx, dw, dstyles, ddcoefs, dnoise, db, None

@@ -55,6 +55,23 @@ def _dot_hw_launch(u, v):
     return part.sum(0) if ns > 1 else part[0]
 
 
+def _dot_hw_scale_launch(u, v, a):
+    """(u * a[n, c], sum_hw u * v) from one pass over u and v (channel-minor, same shape), or None when the shapes do not fit that kernel"""
+    lib = _lib.load()
+    u, layout = _layout(u)
+    n, c, h, w = u.shape
+    if layout != 1 or u.dtype != v.dtype or u.numel() == 0 or not lib.sbg_dot_hw_scale_supported(c):
+        return None
+    v = v.contiguous(memory_format=torch.channels_last)
+    a32 = a.detach().to(torch.float32).reshape(n, c).contiguous()
+    y = torch.empty_like(u)
+    ns = lib.sbg_dot_hw_splits(1, n, c, h * w)
+    part = torch.empty([ns, n, c], dtype=torch.float32, device=u.device)
+    _lib.check(lib.sbg_dot_hw_scale(_lib.ptr(u), _lib.ptr(v), _lib.ptr(a32), _lib.ptr(y), _lib.ptr(part), _lib.dtype_code(u.dtype),
+                                    n, c, h * w, _lib.stream_ptr(u.device)), "sbg_dot_hw_scale")
+    return y, (part[0] if ns == 1 else part.sum(0))
+
+
 class _ScaleNC(torch.autograd.Function):
     """y = x * a[n, c] (+ z[n or 1, 1, h, w]);  a: fp32 [N, C]"""
 
@@ -70,10 +87,16 @@ class _ScaleNC(torch.autograd.Function):
     def backward(ctx, dy):
         x, a = ctx.saved_tensors
         dx = da = dz = None
-        if ctx.needs_input_grad[0]:
-            dx = _ScaleNC.apply(dy, a, None)
-        if ctx.needs_input_grad[1]:
-            da = _DotHW.apply(dy, x).to(a.dtype).reshape(a.shape)
+        both = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not torch.is_grad_enabled() and dy.dtype == x.dtype:
+            both = _dot_hw_scale_launch(dy, x, a)            # first order: both gradients from one pass over (dy, x)
+        if both is not None:
+            dx, da = both[0], both[1].to(a.dtype).reshape(a.shape)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = _ScaleNC.apply(dy, a, None)
+            if ctx.needs_input_grad[1]:
+                da = _DotHW.apply(dy, x).to(a.dtype).reshape(a.shape)
         if ctx.needs_input_grad[2]:
             dz = dy.sum(dim=1, keepdim=True, dtype=torch.float32)
             if ctx.z_shape[0] == 1 or len(ctx.z_shape) == 2:

@@ -316,6 +316,32 @@ def test_fma(dev):
         check(u, v, 1e-5)
 
 
+def test_scale_nc_gradients_in_one_pass(dev):
+    """y = x * a[n, c] (the style modulation in front of every synthesis convolution, reference generators.py:79): first-order backward takes both
+    gradients from ONE pass over (dy, x) (sbg_dot_hw_scale); they must be autograd's `dy * a` and `(dy * x).sum([2, 3])` -- checked against a
+    float64 statement for 16-bit channel-minor tensors (the training layout), fp32, a channel count whose vectors do not tile a workgroup
+    (falls back to the two kernels) and an image larger than one pixel split."""
+    from style_big_gan_amd.torch_utils.ops import modulate
+    torch.manual_seed(11)
+    for dtype, n, c, h, w in ((torch.bfloat16, 3, 64, 20, 24), (torch.bfloat16, 2, 128, 96, 96), (torch.float32, 2, 32, 9, 7), (torch.bfloat16, 2, 24, 8, 8)):
+        x = torch.randn(n, c, h, w).to(dtype); a = torch.randn(n, c) + 1; dy = torch.randn(n, c, h, w).to(dtype)
+        xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True); ag = a.to(dev).requires_grad_(True)
+        y = modulate.scale_nc(xg, ag)
+        gx, ga = torch.autograd.grad(y, [xg, ag], dy.to(dev).contiguous(memory_format=torch.channels_last))
+        x64, dy64, a64 = x.double(), dy.double(), a.double()
+        tol = 1e-5 if dtype == torch.float32 else 1e-2
+        check(y, (x64 * a64[:, :, None, None]).float(), tol, f"scale_nc {dtype} {c}")
+        check(gx, (dy64 * a64[:, :, None, None]).float(), tol, f"scale_nc dx {dtype} {c}")
+        check(ga, (dy64 * x64).sum([2, 3]).float(), 1e-5 if dtype == torch.float32 else 2e-3, f"scale_nc da {dtype} {c}")
+    # the second-order path (composition of differentiable ops) still agrees with the fused first-order one
+    xg = torch.randn(2, 64, 12, 12, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ag = (torch.randn(2, 64, device=dev) + 1).requires_grad_(True)
+    dyg = torch.randn(2, 64, 12, 12, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    first = torch.autograd.grad(modulate.scale_nc(xg, ag), [xg, ag], dyg)
+    second = torch.autograd.grad(modulate.scale_nc(xg, ag), [xg, ag], dyg, create_graph=True)
+    check(first[0], second[0].detach().float().cpu(), 1e-6); check(first[1], second[1].detach().float().cpu(), 1e-4)
+
+
 def test_conv_k64_halo_and_gather_kernels(dev):
     """shapes large enough (>= 256 tiles of 128 x 256) to take the persistent halo-staged kernels of csrc/conv_k64.hip
     -- (8, 32) patches with W % 32 == 0, (16, 16) patches otherwise -- and the 128 x 256 gather kernel, with ragged channel counts
