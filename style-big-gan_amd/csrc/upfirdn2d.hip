@@ -627,8 +627,26 @@ static int launch_upfirdn(const UpfirdnArgs& a0, bool vec8, bool exact16, hipStr
     SbgProfScope prof(stream, SBG_K_UPFIRDN2D, 0.0,
                       es * ((double)a.N * a.C * a.inH * a.inW + (double)a.N * a.C * a.outH * a.outW),
                       {a.N, a.C, a.inH, a.inW, a.outH, a.outW, a.upx * 16 + a.downx});
-    if (vec8 && exact16 && sizeof(T) == 2 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw == 4 && a.fh == 4 && (a.C % 64) == 0
-        && a.outW >= 16 && a.outH >= 8 && sbg_env("SBG_FIR_NO_MFMA") == nullptr && try_fir_mfma<T>(a, stream)) {
+    const bool mfma_ok = vec8 && exact16 && sizeof(T) == 2 && a.upx == 1 && a.upy == 1 && a.downx == 1 && a.downy == 1 && a.fw == 4 && a.fh == 4 && (a.C % 64) == 0
+                         && a.outW >= 16 && a.outH >= 8 && sbg_env("SBG_FIR_NO_MFMA") == nullptr;
+    // A few columns beyond a multiple of the 32-column strips (the 2 res + 1 wide outputs of the discriminator's low-pass in front of a strided
+    // convolution: 257 = 8 strips + 1) would cost a whole strip of matrix-core work (9 strips for 257 columns: 11 % idle, 33 columns: 48 %): the
+    // strips take the multiple of 32 and the register-blocked kernel the remaining columns, as a launch over the shifted sub-rectangle.
+    const int rem = a.outW % 32;
+    static const char* no_edge = sbg_env("SBG_FIR_NO_EDGE");
+    if (mfma_ok && !a.tail && !no_edge && rem >= 1 && rem <= 4 && a.outW > 32) {
+        UpfirdnArgs m = a, e = a;
+        m.outW = a.outW - rem;
+        e.outW = rem; e.padx0 = a.padx0 - m.outW; e.y = (void*)((T*)a.y + (int64_t)m.outW * a.osx);
+        if (try_fir_mfma<T>(m, stream)) {
+            const int xblocks = (e.outW + FIR_TX - 1) / FIR_TX, yblocks = (e.outH + FIR_TY - 1) / FIR_TY;
+            e.total = (int64_t)e.N * yblocks * xblocks * (e.C >> 3);
+            SBG_LAUNCH((upfirdn2d_fir_fixed_kernel<T, 4, 4>), dim3(sbg_stream_grid(e.total, 256)), dim3(256), 0, stream, e, xblocks, yblocks);
+            SBG_HIP_LAUNCH_CHECK();
+            return SBG_OK;
+        }
+    }
+    if (mfma_ok && try_fir_mfma<T>(a, stream)) {
         // matrix-core FIR
     } else if (a.tail) {
         return sbg_fail(SBG_ERR_UNSUPPORTED, "upfirdn2d: fused tail requested but the matrix-core FIR path does not take this launch");
