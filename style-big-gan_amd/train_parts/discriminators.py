@@ -297,9 +297,48 @@ class Discriminator(torch.nn.Module):
         blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
         return max(int(b.conv1.weight.shape[1]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 4) for b in blocks)
 
+    pass_bytes_limit = 1 << 31      # the op layer addresses tensors below 2 GiB (and, at two bytes per element, below 2^31 elements)
+
+    def pass_plan(self, n):
+        """How a pass over n samples stays below `pass_bytes_limit` per tensor: (k, chunk) = the k highest-resolution blocks run over slices of
+        `chunk` samples, their outputs are concatenated and the remaining blocks see the whole batch; (0, n) = no slicing; None = not possible.
+        The blocks treat samples independently (only the epilogue's minibatch-std layer looks across the batch), so slicing them changes nothing
+        but the launch sizes -- while the low-resolution blocks, whose cost is per launch rather than per sample, still run once.  Only for
+        architectures whose blocks hand nothing but `x` to the next block ('orig', 'resnet': the image is consumed by the first block)."""
+        cache = self.__dict__.setdefault('_pass_plans', {})
+        key = (n, self.pass_bytes_limit)
+        if key not in cache:
+            cache[key] = self._pass_plan(n)
+        return cache[key]
+
+    def _pass_plan(self, n):
+        blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
+        peaks = [int(b.conv1.weight.shape[1]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 4) for b in blocks]
+        k = 0
+        while k < len(peaks) and n * peaks[k] >= self.pass_bytes_limit:
+            k += 1
+        if k == 0:
+            return 0, n
+        if any(b.architecture == 'skip' or b.attention is not None for b in blocks[:k]):
+            return None
+        for chunk in range(n // 2, 0, -1):
+            if n % chunk == 0 and chunk * max(peaks[:k]) < self.pass_bytes_limit:
+                return k, chunk
+        return None
+
     def forward(self, img, c, **block_kwargs):
         x = None
-        for res in self.block_resolutions:
+        plan = self.pass_plan(img.shape[0]) if img.shape[0] > 1 else None
+        lead, chunk = plan if plan is not None else (0, img.shape[0])
+        if lead > 0:
+            parts = []
+            for part in img.split(chunk):
+                xp = None
+                for res in self.block_resolutions[:lead]:
+                    xp, part = getattr(self, f'b{res}')(xp, part, **block_kwargs)
+                parts.append(xp)
+            x, img = torch.cat(parts), None
+        for res in self.block_resolutions[lead:]:
             x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
         cmap = self.mapping(None, c) if (self.c_dim is not None and self.c_dim > 0) else None
         return self.b4(x, img, cmap)

@@ -42,7 +42,6 @@ _scope = torch.autograd.profiler.record_function
 import os as _os
 merge_d_passes = _os.environ.get('SBG_MERGE_D', '1') != '0'      # Dmain: one discriminator pass over [generated; real] (see _pass_d_adv)
 _order_cache = {}
-_PASS_BYTES = 1 << 31      # no tensor of a pass may reach 2 GiB (and, at two bytes per element, 2^31 elements: the op layer's limit)
 
 #             phase      passes, in execution order
 _PROGRAMS = {'Gmain': ('g_adv',), 'Greg': ('g_reg',), 'Gboth': ('g_adv', 'g_reg'),
@@ -171,7 +170,7 @@ class LossBase:
     # augmentation pipe still sees generated images, then reals (its random draws keep that order), and the samples are interleaved so that the
     # minibatch-std layer forms exactly the groups it forms on each segment alone (Discriminator.merged_batch_order).  Only for discriminators
     # that declare `batch_mergeable` (no state carried across forward calls) and while no tensor of the pass reaches the op layer's 2 GiB
-    # limit.  Worth it because the fixed cost of a pass -- ~600 launches, the latency-bound 4x4 ... 32x32 layers -- is paid once: see
+    # limit (Discriminator.pass_plan: the highest-resolution blocks may run over slices of the pass to stay below it).  Worth it because the fixed cost of a pass -- ~600 launches, the latency-bound 4x4 ... 32x32 layers -- is paid once: see
     # DESIGN.md, "passes per round".
     def _d_order(self, n, segments, device):
         """(fwd, inv) index tensors for a pass over `segments` batches of n samples; () = natural order; None = not possible"""
@@ -183,8 +182,8 @@ class LossBase:
         key = (id(d), n, segments, device)
         hit = _order_cache.get(key)
         if hit is None:
-            peak = d.peak_activation_bytes() if hasattr(d, 'peak_activation_bytes') else 0
-            order = d.merged_batch_order(n, segments) if segments * n * peak < _PASS_BYTES else None
+            fits = d.pass_plan(segments * n) is not None if hasattr(d, 'pass_plan') else True
+            order = d.merged_batch_order(n, segments) if fits else None
             if order is None:
                 hit = (None, None)
             else:
