@@ -27,18 +27,17 @@ def main(argv=None, max_iterations=None):
     return trainer
 
 
+# the trainer lifecycle the reference drives on every rank (starter.py:32-45); a trainer class may override any stage
+LIFECYCLE = ("setup_logs", "distribute_torch", "init_params", "setup_dataset", "setup_networks", "setup_augmentations", "distrib_acrros_gpu",
+             "setup_training_phases", "export_sample_images", "training_loop")
+_STAGE_ARGS = {"distribute_torch": lambda temp_dir, max_iterations: (temp_dir,), "training_loop": lambda temp_dir, max_iterations: (max_iterations,)}
+
+
 def multiprocesses_main(rank, trainer, temp_dir, max_iterations=None):
+    """one rank: every lifecycle stage in order"""
     trainer.rank = rank
-    trainer.setup_logs()
-    trainer.distribute_torch(temp_dir)
-    trainer.init_params()
-    trainer.setup_dataset()
-    trainer.setup_networks()
-    trainer.setup_augmentations()
-    trainer.distrib_acrros_gpu()
-    trainer.setup_training_phases()
-    trainer.export_sample_images()
-    trainer.training_loop(max_iterations)
+    for stage in LIFECYCLE:
+        getattr(trainer, stage)(*_STAGE_ARGS.get(stage, lambda *_: ())(temp_dir, max_iterations))
 
 
 if __name__ == "__main__":
