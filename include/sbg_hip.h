@@ -79,8 +79,17 @@ typedef struct sbg_upfirdn2d_params {
     int act; float alpha, act_gain, clamp;
     int     filter_exact16;  /* hint: every tap of f is exactly representable in `dtype` (bf16 / f16), so the filter may be fed to the
                                 matrix cores without rounding ([1,3,3,1]-type filters are); 0 = unknown -> fp32 vector path */
+    /* Optional backward tail (excludes the forward tail above).  In the backward of `bias_act -> low-pass` -- a discriminator block's conv0 followed by
+     * the filter of its down-sampling conv1, train_parts/discriminators.py:286-291 -- this launch is the transposed low-pass and its result is the
+     * gradient w.r.t. the bias_act's OUTPUT `dact_y` (saved; this launch's output geometry).  With dact_y != NULL the kernel multiplies that result by
+     * the slope of clamp(act(.) * dact_gain) at dact_y (bias_act.py:159-210 for the piecewise-linear activations: dact_gain above zero,
+     * dact_gain * dact_alpha below for lrelu, zero where |y| >= dact_clamp; dact_clamp < 0 disables) and accumulates it per channel -- the bias
+     * gradient: dact_partial[r][64] for r < sbg_upfirdn2d_dact_rows(), row r = ((n * ysegs + s) * xstrips + x) * (C / 64) + channel block, to be summed
+     * over everything but the channel block by the caller.  Sliding-window matrix-core FIR only: _dact_rows() returns -1 for other launches. */
+    const void* dact_y; float* dact_partial; int dact_act; float dact_alpha, dact_gain, dact_clamp;
 } sbg_upfirdn2d_params;
 int sbg_upfirdn2d_tail_supported(const sbg_upfirdn2d_params* p);
+int64_t sbg_upfirdn2d_dact_rows(const sbg_upfirdn2d_params* p);
 int sbg_upfirdn2d(const sbg_upfirdn2d_params* p, sbg_stream_t stream);
 
 /* Separable filter (1-D `f` of `taps` taps applied along both axes) in one launch -- replaces the reference's two plugin calls

@@ -37,6 +37,8 @@ class UpfirdnParams(ctypes.Structure):
         ("oscale", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("noise_stride_n", ctypes.c_int64), ("bias", ctypes.c_void_p),
         ("act", ctypes.c_int), ("alpha", ctypes.c_float), ("act_gain", ctypes.c_float), ("clamp", ctypes.c_float),
         ("filter_exact16", ctypes.c_int),
+        ("dact_y", ctypes.c_void_p), ("dact_partial", ctypes.c_void_p), ("dact_act", ctypes.c_int),
+        ("dact_alpha", ctypes.c_float), ("dact_gain", ctypes.c_float), ("dact_clamp", ctypes.c_float),
     ]
 
 
@@ -104,6 +106,7 @@ SYMBOLS = [
                                                    _c.c_int64, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_upfirdn2d_tail_supported", _c.c_int, [_c.POINTER(UpfirdnParams)]),
     ("sbg_upfirdn2d", _c.c_int, [_c.POINTER(UpfirdnParams), _c.c_void_p]),
+    ("sbg_upfirdn2d_dact_rows", _c.c_int64, [_c.POINTER(UpfirdnParams)]),
     ("sbg_upfirdn2d_separable_supported", _c.c_int, [_c.c_int] * 3),
     ("sbg_upfirdn2d_separable", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 11 + [_c.c_float, _c.c_void_p]),
     ("sbg_conv2d_igemm_workspace", _c.c_int64, [_c.POINTER(ConvParams)]),

@@ -28,6 +28,10 @@ struct UpfirdnArgs {
     // fused tail (matrix-core FIR only): y = clamp(act(fir * gain * oscale[n, c] + noise[n, pixel] + bias[c]) * act_gain)
     const float* oscale; const float* noise; int64_t noise_sn; const float* bias;
     int tail; float alpha, act_gain, clamp;
+    // backward tail (sliding-window matrix-core FIR only; tail == 2): the result is the gradient w.r.t. the OUTPUT y of a bias_act (`dact_y`, saved,
+    // same geometry as this launch's output); the kernel multiplies by the activation's slope at y -- dact_gpos for y > 0, dact_gneg below, zero on the
+    // clamp rails |y| >= dact_rail -- and adds up the result per channel (the bias gradient): dact_part[workgroup][64]
+    const void* dact_y; float* dact_part; float dact_gpos, dact_gneg, dact_rail;
 };
 
 #define SBG_UPFIRDN_MAX_LDS_TAPS 1024
@@ -261,12 +265,14 @@ template <> struct FirMfma<bf16_s> {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ short bits(float v) { return (short)f32_to_bf16_bits(v); }
+    static __device__ __forceinline__ float from_bits(unsigned short b) { return bf16_bits_to_f32(b); }
 };
 template <> struct FirMfma<f16_s> {
     static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ short bits(float v) { return (short)f32_to_f16_bits(v); }
+    static __device__ __forceinline__ float from_bits(unsigned short b) { return f16_bits_to_f32(b); }
 };
 
 template <class T, int RPW>      // RPW = output rows per wave: 2 (8 x 32 tile, 68 KB of LDS, 2 workgroups per CU) or 1 (4 x 32 tile, 43 KB, 3 per CU)
@@ -416,7 +422,9 @@ __global__ __launch_bounds__(256, RPW == 1 ? 3 : (RPW == 2 ? 2 : 1)) void upfird
 // MFMAs of step s and the stores of step s - 1 are in flight together (two workgroups per CU: 72 KB of LDS each).
 // Order inside a step: issue the prefetch -> compute from LDS -> wait for the prefetch (the stores of the previous step, issued a whole step
 // ago, have drained by then) -> barrier (every wave is done with the rows the NEXT prefetch overwrites, and sees the new rows) -> store.
-template <class T>
+// BT (backward tail): see UpfirdnArgs::dact_y -- the transposed low-pass in the backward of `bias_act -> low-pass` (D's conv0 -> the filter in front of the
+// strided conv1) hands its result straight to the activation gradient, so the gradient w.r.t. the activation's output is never written or re-read.
+template <class T, bool BT>
 __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs p, unsigned x_bytes, int tiles_x, int cblocks, int ysegs, int seg_rows)
 {
     constexpr int TX = 32, FH = 4, FW = 4, SR = 4;      // SR = output rows per step (one per wave)
@@ -498,10 +506,28 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
 #pragma unroll
         for (int c = 0; c < 4; c++) t_bias[c] = *reinterpret_cast<const float4_t*>(p.bias + cb0 * 64 + c * 16 + 4 * fg);
     }
+    typedef __attribute__((ext_vector_type(4))) unsigned uint4_t;
+    const T* ysv = BT ? (const T*)p.dact_y + n * p.osn + cb0 * 64 + (fg & 1) * 16 + (fg >> 1) * 8 : nullptr;      // the store layout of this lane (see below)
+    const float d_gpos = p.dact_gpos, d_gneg = p.dact_gneg, d_rail = p.dact_rail;
+    float4_t dbacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) dbacc[c] = float4_t{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int s = 0; s < nsteps; s++) {
+        uint4_t ysave[2][2];
+        if (BT) {       // the saved activations of this step's outputs, in the (coalesced, 16 B per lane) layout the stores use; issued ahead of the prefetch
+            const int oy_ = oy_begin + SR * s + wave;
+#pragma unroll
+            for (int sg = 0; sg < 2; sg++) {
+                const int ox_ = ox0 + sg * 16 + fi;
+                const bool ok_ = oy_ < oy_end && ox_ < p.outW;
+                const T* src = ysv + (ok_ ? oy_ * p.osy + ox_ * p.osx : 0);
+#pragma unroll
+                for (int h = 0; h < 2; h++) ysave[sg][h] = *reinterpret_cast<const uint4_t*>(src + h * 32);
+            }
+        }
         if (s + 1 < nsteps) fetch_rows(SR * (s + 1) + FH - 1, SR * (s + 2) + FH - 1);       // the four new rows of the next window
         float4_t acc[2][4];
 #pragma unroll
@@ -541,6 +567,29 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
         for (int sg = 0; sg < 2; sg++) {
             const int ox = ox0 + sg * 16 + fi;
             const bool okp = oy < oy_end && ox < p.outW;
+            if constexpr (BT) {
+                // undo the store permutation on the saved activations: swapping is its own inverse, so the pair (c, c + 1) comes back from the same instruction
+                unsigned yk[4][2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const auto q0 = __builtin_amdgcn_permlane16_swap(ysave[sg][h][0], ysave[sg][h][2], false, false);
+                    const auto q1 = __builtin_amdgcn_permlane16_swap(ysave[sg][h][1], ysave[sg][h][3], false, false);
+                    yk[2 * h][0] = q0[0]; yk[2 * h + 1][0] = q0[1]; yk[2 * h][1] = q1[0]; yk[2 * h + 1][1] = q1[1];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float4_t v = acc[sg][c] * t_scale[c];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float yv = FirMfma<T>::from_bits((unsigned short)(yk[c][e >> 1] >> ((e & 1) * 16)));
+                        const float slope = (fabsf(yv) < d_rail) ? (yv > 0.f ? d_gpos : d_gneg) : 0.f;
+                        v[e] *= slope;
+                        dbacc[c][e] += okp ? v[e] : 0.f;
+                    }
+                    pk[sg][c][0] = (unsigned)(unsigned short)FirMfma<T>::bits(v[0]) | ((unsigned)(unsigned short)FirMfma<T>::bits(v[1]) << 16);
+                    pk[sg][c][1] = (unsigned)(unsigned short)FirMfma<T>::bits(v[2]) | ((unsigned)(unsigned short)FirMfma<T>::bits(v[3]) << 16);
+                }
+            } else {
             const float nz = (p.tail && p.noise && okp) ? p.noise[n * p.noise_sn + (int64_t)oy * p.outW + ox] : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -549,6 +598,7 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
                 for (int e = 0; e < 4; e++) { float u = v[e]; u = (u > 0.f) ? u : u * t_alpha; v[e] = __builtin_amdgcn_fmed3f(u * t_gain, -t_cl, t_cl); }
                 pk[sg][c][0] = (unsigned)(unsigned short)FirMfma<T>::bits(v[0]) | ((unsigned)(unsigned short)FirMfma<T>::bits(v[1]) << 16);
                 pk[sg][c][1] = (unsigned)(unsigned short)FirMfma<T>::bits(v[2]) | ((unsigned)(unsigned short)FirMfma<T>::bits(v[3]) << 16);
+            }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the prefetch has landed (and the previous step's stores drained)
@@ -568,6 +618,38 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
             }
         }
     }
+    if constexpr (BT) {
+        // per-channel sums of this workgroup (fixed order): over the 16 pixel lanes of a row by DPP rotates, then over the four waves through LDS
+        __syncthreads();                                 // the ring is no longer read
+        float* red = reinterpret_cast<float*>(fsm);      // [4 waves][64 channels]
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float a = dbacc[c][e];
+                a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false));    // row_ror:8
+                a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x124, 0xf, 0xf, false));    // row_ror:4
+                a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x122, 0xf, 0xf, false));    // row_ror:2
+                a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x121, 0xf, 0xf, false));    // row_ror:1
+                if (fi == 0) red[wave * 64 + c * 16 + 4 * fg + e] = a;
+            }
+        __syncthreads();
+        if (tid < 64) p.dact_part[(int64_t)blockIdx.x * 64 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    }
+}
+
+// strip / segment geometry of the sliding-window kernel (shared by the launcher and by sbg_upfirdn2d_dact_rows)
+static bool fir_slide_geometry(const UpfirdnArgs& a, int& tiles_x, int& cblocks, int& ysegs, int& seg_rows, int64_t& nblk)
+{
+    tiles_x = (a.outW + 31) / 32; cblocks = a.C / 64;
+    const int64_t strips = (int64_t)a.N * tiles_x * cblocks;
+    // vertical segments: enough workgroups for two per CU on every CU, but at least 16 output rows per segment (3 overlap rows are re-read per segment)
+    ysegs = 1;
+    while (strips * ysegs < 1024 && a.outH / (ysegs * 2) >= 16) ysegs *= 2;
+    seg_rows = (((a.outH + ysegs - 1) / ysegs) + 3) & ~3;
+    ysegs = (a.outH + seg_rows - 1) / seg_rows;
+    nblk = strips * ysegs;
+    return nblk <= INT32_MAX && nblk > 0;
 }
 
 template <class T>
@@ -576,18 +658,17 @@ static bool launch_fir_slide(const UpfirdnArgs& a, hipStream_t stream)
     constexpr int lds = 12 * 48 * 128;
     const int64_t x_bytes = 2 * ((int64_t)(a.N - 1) * a.isn + (int64_t)(a.inH - 1) * a.isy + (int64_t)(a.inW - 1) * a.isx + a.C);
     if (x_bytes >= (int64_t)SBG_FIR_OOB || a.isn < 0 || a.isy < 0 || a.isx < 0) return false;
-    const int tiles_x = (a.outW + 31) / 32, cblocks = a.C / 64;
-    const int64_t strips = (int64_t)a.N * tiles_x * cblocks;
-    // vertical segments: enough workgroups for two per CU on every CU, but at least 16 output rows per segment (3 overlap rows are re-read per segment)
-    int ysegs = 1;
-    while (strips * ysegs < 1024 && a.outH / (ysegs * 2) >= 16) ysegs *= 2;
-    const int seg_rows = (((a.outH + ysegs - 1) / ysegs) + 3) & ~3;
-    ysegs = (a.outH + seg_rows - 1) / seg_rows;
-    const int64_t nblk = strips * ysegs;
-    if (nblk > INT32_MAX || nblk <= 0) return false;
-    auto kern = upfirdn2d_fir_slide_kernel<T>;
-    if (!SBG_RAISE_LDS_ONCE(kern, lds)) return false;
-    SBG_LAUNCH_OR(return false, kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, cblocks, ysegs, seg_rows);
+    int tiles_x, cblocks, ysegs, seg_rows; int64_t nblk;
+    if (!fir_slide_geometry(a, tiles_x, cblocks, ysegs, seg_rows, nblk)) return false;
+    if (a.tail == 2) {
+        auto kern = upfirdn2d_fir_slide_kernel<T, true>;
+        if (!SBG_RAISE_LDS_ONCE(kern, lds)) return false;
+        SBG_LAUNCH_OR(return false, kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, cblocks, ysegs, seg_rows);
+    } else {
+        auto kern = upfirdn2d_fir_slide_kernel<T, false>;
+        if (!SBG_RAISE_LDS_ONCE(kern, lds)) return false;
+        SBG_LAUNCH_OR(return false, kern, dim3((unsigned)nblk), dim3(256), lds, stream, a, (unsigned)x_bytes, tiles_x, cblocks, ysegs, seg_rows);
+    }
     return true;
 }
 
@@ -610,6 +691,7 @@ template <class T>
 static bool launch_fir_mfma(const UpfirdnArgs& a, hipStream_t stream)
 {
     static const char* e = sbg_env("SBG_FIR_RPW");        // experiment switch: tile kernels (1 = 4 x 32 tiles, 2 = 8 x 32, 4 = 16 x 32) instead of the sliding window
+    if (a.tail == 2) return a.outH >= 16 && launch_fir_slide<T>(a, stream);      // the backward tail exists in the sliding-window kernel only
     if (!e && a.outH >= 16) return launch_fir_slide<T>(a, stream);
     if (e && atoi(e) == 1) return launch_fir_mfma_rpw<T, 1>(a, stream);
     if (e && atoi(e) == 4) return launch_fir_mfma_rpw<T, 4>(a, stream);
@@ -679,6 +761,19 @@ extern "C" int sbg_upfirdn2d_tail_supported(const sbg_upfirdn2d_params* q)
            && q->inStride[2] == 1 && q->outStride[2] == 1 && sbg_env("SBG_FIR_NO_MFMA") == nullptr;
 }
 
+// Rows of `dact_partial` (= workgroups of the sliding-window launch) for a launch with a backward tail, or -1 when that kernel does not take it.
+extern "C" int64_t sbg_upfirdn2d_dact_rows(const sbg_upfirdn2d_params* q)
+{
+    if (!q || !sbg_upfirdn2d_tail_supported(q) || q->outSize[1] < 16 || sbg_env("SBG_FIR_RPW") != nullptr) return -1;
+    if (q->inStride[0] < 0 || q->inStride[1] < 0 || q->inStride[3] < 0) return -1;
+    const int64_t x_bytes = 2 * ((int64_t)(q->inSize[3] - 1) * q->inStride[3] + (int64_t)(q->inSize[1] - 1) * q->inStride[1] + (int64_t)(q->inSize[0] - 1) * q->inStride[0] + q->inSize[2]);
+    if (x_bytes >= (int64_t)SBG_FIR_OOB) return -1;
+    UpfirdnArgs a = {};
+    a.outW = q->outSize[0]; a.outH = q->outSize[1]; a.C = q->inSize[2]; a.N = q->inSize[3];
+    int tiles_x, cblocks, ysegs, seg_rows; int64_t nblk;
+    return fir_slide_geometry(a, tiles_x, cblocks, ysegs, seg_rows, nblk) ? nblk : -1;
+}
+
 extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)
 {
     SBG_CHECK(q != nullptr && q->x != nullptr && q->f != nullptr && q->y != nullptr, "upfirdn2d: null pointer");
@@ -707,6 +802,17 @@ extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)
     a.oscale = q->oscale; a.noise = q->noise; a.noise_sn = q->noise_stride_n; a.bias = q->bias;
     a.tail = (q->act != 0) ? 1 : 0;
     a.alpha = q->act == SBG_ACT_LRELU ? q->alpha : (q->act == SBG_ACT_RELU ? 0.f : 1.f); a.act_gain = q->act_gain; a.clamp = q->clamp;
+    a.dact_y = nullptr; a.dact_part = nullptr; a.dact_gpos = a.dact_gneg = 1.f; a.dact_rail = __builtin_inff();
+    if (q->dact_y) {        // backward tail: slope of clamp(act(.) * gain) at the saved output (same tests as sbg_modconv_bwd)
+        SBG_CHECK(q->act == 0, "upfirdn2d: forward and backward tails exclude each other");
+        SBG_CHECK(q->dact_partial != nullptr, "upfirdn2d: the backward tail needs dact_partial (sbg_upfirdn2d_dact_rows() x 64 floats)");
+        SBG_CHECK(q->dact_act == SBG_ACT_LINEAR || q->dact_act == SBG_ACT_RELU || q->dact_act == SBG_ACT_LRELU, "upfirdn2d: backward-tail activation must be linear, relu or lrelu");
+        SBG_CHECK(q->dact_gain > 0.f && sbg_aligned16(q->dact_y), "upfirdn2d: backward tail: gain must be positive, dact_y 16-byte aligned");
+        a.tail = 2; a.dact_y = q->dact_y; a.dact_part = q->dact_partial;
+        a.dact_gpos = q->dact_gain;
+        a.dact_gneg = q->dact_act == SBG_ACT_LRELU ? q->dact_gain * q->dact_alpha : (q->dact_act == SBG_ACT_RELU ? 0.f : q->dact_gain);
+        a.dact_rail = q->dact_clamp >= 0.f ? q->dact_clamp : __builtin_inff();
+    }
 
     // 8-channel vector path: channel-minor on both sides, every pixel start 16-B aligned.
     const int es = sbg_dtype_size(q->dtype);
@@ -716,7 +822,9 @@ extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)
                 (es == 2 || ((a.isx | a.isy | a.isn | a.osx | a.osy | a.osn) % 4) == 0);
     hipStream_t s = (hipStream_t)stream;
     const bool exact16 = q->filter_exact16 != 0;
-    if (a.tail) {
+    if (a.tail == 2) {
+        SBG_CHECK(vec8 && sbg_upfirdn2d_dact_rows(q) > 0, "upfirdn2d: the backward tail needs the sliding-window matrix-core FIR (sbg_upfirdn2d_dact_rows)");
+    } else if (a.tail) {
         SBG_CHECK(q->act == SBG_ACT_LINEAR || q->act == SBG_ACT_RELU || q->act == SBG_ACT_LRELU, "upfirdn2d: fused activation must be linear, relu or lrelu");
         SBG_CHECK(vec8 && sbg_upfirdn2d_tail_supported(q), "upfirdn2d: the fused tail needs the matrix-core FIR path (sbg_upfirdn2d_tail_supported)");
         SBG_CHECK((!q->oscale || sbg_aligned16(q->oscale)) && (!q->bias || sbg_aligned16(q->bias)), "upfirdn2d: oscale / bias must be 16-byte aligned");

@@ -36,8 +36,15 @@ def _tail(y, tail):
     return bias_act.bias_act(y, b, act=tail["act"], alpha=tail["alpha"], gain=tail["gain"], clamp=tail["clamp"])
 
 
+def lowpass_padding(f, down, padding):
+    """[px0, px1, py0, py1] of the low-pass that conv2d_resample(..., up=1, down=down, padding) applies in front of its strided convolution"""
+    fw, fh = _get_filter_size(f)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    return [px0 + (fw - down + 1) // 2, px1 + (fw - down) // 2, py0 + (fh - down + 1) // 2, py1 + (fh - down) // 2]
+
+
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False, bias_act_tail=None, fir_tail=None,
-                    wgain=1.0):
+                    wgain=1.0, prefiltered=False):
     """x: [N, Cin, H, W]; w: [Cout, Cin // groups, kh, kw] (same dtype); f: filter from upfirdn2d.setup_filter().
     `padding` is relative to the upsampled image.  Returns [N, Cout, H * up // down (+ padding), ...].
     `bias_act_tail` (extension): dict(b, act, alpha, gain, clamp) -- apply that bias_act to the result, fused into the
@@ -54,6 +61,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
     assert isinstance(up, int) and up >= 1 and isinstance(down, int) and down >= 1
     assert isinstance(groups, int) and groups >= 1
+    assert not prefiltered or (up == 1 and down > 1 and w.shape[2] > 1)
     cout, cin_g, kh, kw = [int(s) for s in w.shape]
     fw, fh = _get_filter_size(f)
     px0, px1, py0, py1 = _parse_padding(padding)
@@ -77,7 +85,8 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         return _tail(upfirdn2d.upfirdn2d(x, f, up=up, padding=pad4, gain=up ** 2, flip_filter=flip_filter), tail)
 
     if down > 1 and up == 1:                        # low-pass at full resolution, then a strided convolution
-        x = upfirdn2d.upfirdn2d(x, f, padding=pad4, flip_filter=flip_filter)
+        if not prefiltered:                         # (`prefiltered`, extension: x already is upfirdn2d(., f, lowpass_padding(f, down, padding)) -- the
+            x = upfirdn2d.upfirdn2d(x, f, padding=pad4, flip_filter=flip_filter)      # producer applied it, conv_bias_act.conv2d_bias_act_fir)
         return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight, tail=tail, wgain=wgain)
 
     if up > 1:                                      # transposed strided convolution, then low-pass (and optional decimation)

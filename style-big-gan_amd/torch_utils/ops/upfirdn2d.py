@@ -69,10 +69,12 @@ def setup_filter(f, device=torch.device("cpu"), normalize=True, flip_filter=Fals
     return f.to(device=device)
 
 
-def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, tail=None, probe=False):
+def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, tail=None, probe=False, dact=None):
     """One sbg_upfirdn2d launch on a rank-2 filter; output keeps x's memory format (reference: upfirdn2d.cpp:35).
     `tail` = dict(oscale, noise, bias, act, alpha, gain, clamp): fused demodulation / noise / bias_act epilogue (matrix-core FIR path only);
-    `probe=True` returns whether that path would take this launch with a tail, without launching."""
+    `probe=True` returns whether that path would take this launch with a tail, without launching.
+    `dact` = dict(y, act, alpha, gain, clamp): backward tail -- the result is multiplied by the slope of that bias_act at its saved output y and summed
+    per channel; returns (result, bias gradient [C] fp32), or None when the sliding-window matrix-core FIR does not take the launch."""
     lib = _lib.load()
     if x.ndim != 4:
         raise RuntimeError("upfirdn2d: x must be rank 4")
@@ -103,6 +105,17 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     p.filter_exact16 = int(x.dtype != torch.float32 and upx == upy == downx == downy == 1 and (fh, fw) == (4, 4) and _taps_exact(f2d, x.dtype))
     if probe:
         return bool(cl and lib.sbg_upfirdn2d_tail_supported(p))
+    if dact is not None:
+        ys = dact["y"]
+        rows = int(lib.sbg_upfirdn2d_dact_rows(p)) if cl else -1
+        if rows <= 0 or ys.shape != y.shape or ys.dtype != y.dtype or ys.stride() != y.stride():
+            return None
+        part = torch.empty([rows, 64], dtype=torch.float32, device=x.device)
+        p.dact_y, p.dact_partial = ys.data_ptr(), part.data_ptr()
+        p.dact_act = {"linear": 1, "relu": 2, "lrelu": 3}[dact["act"]]
+        p.dact_alpha, p.dact_gain, p.dact_clamp = float(dact["alpha"]), float(dact["gain"]), float(dact["clamp"])
+        _lib.check(lib.sbg_upfirdn2d(p, _lib.stream_ptr(x.device)), "sbg_upfirdn2d")
+        return y, part.reshape(-1, c // 64, 64).sum(0).reshape(c)       # rows: (sample, segment, strip) x channel block; fixed order
     keep = []
     if tail is not None:
         def f32(t, shape):
@@ -289,6 +302,21 @@ class _FirBiasAct(torch.autograd.Function):
             gcfg = (1, 1, 1, 1, fw - padx0 - 1, iw - ow + padx0, fh - pady0 - 1, ih - oh + pady0, not flip, gain)
             dt = _Upfirdn2d.apply(d2, f, gcfg)
         return dt, None, ddc, dnoise, db, None
+
+
+def fir_transposed_dact(dy, f, cfg, in_hw, y_saved, act, alpha, gain, clamp):
+    """Backward of `bias_act -> upfirdn2d(f, cfg)` with respect to the bias_act's pre-activation, in ONE launch: the transposed low-pass of dy
+    (what _Upfirdn2d.backward computes) times the activation's slope at the saved output, plus the bias gradient.  up = down = 1 only.
+    Returns (gradient [like y_saved], db [C] fp32) or None when the launch does not fit the sliding-window matrix-core FIR."""
+    upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, fgain = cfg
+    if (upx, upy, downx, downy) != (1, 1, 1, 1) or f is None or f.ndim != 2 or dy.device.type != "cuda":
+        return None
+    ih, iw = in_hw
+    fw, fh = _get_filter_size(f)
+    oh, ow = dy.shape[2], dy.shape[3]
+    dy = dy.to(y_saved.dtype).contiguous(memory_format=torch.channels_last)
+    return _launch(dy, f, 1, 1, 1, 1, fw - padx0 - 1, iw - ow + padx0, fh - pady0 - 1, ih - oh + pady0, not flip, fgain,
+                   dact=dict(y=y_saved, act=act, alpha=alpha, gain=gain, clamp=clamp))
 
 
 def fir_tail_supported(x, f, padding, flip_filter=False):

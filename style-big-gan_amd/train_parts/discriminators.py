@@ -12,7 +12,7 @@ import torch
 
 from .. import utils
 from ..torch_utils import misc
-from ..torch_utils.ops import fromrgb, upfirdn2d
+from ..torch_utils.ops import conv2d_gradfix, conv_bias_act, fromrgb, upfirdn2d
 from . import generators as _g
 from .generators import Conv2dLayer, FullyConnectedLayer, MappingNetwork
 
@@ -96,8 +96,14 @@ class DiscriminatorBlock(torch.nn.Module):
         # conv0 -> conv1 (low-pass + stride 2); 'resnet' adds the 1x1 down-sampling shortcut, both branches scaled by sqrt(1/2)
         residual = self.architecture == 'resnet'
         shortcut = self.skip(x, gain=np.sqrt(0.5)) if residual else None
-        x = self.conv0(x)
-        x = self.conv1(x, gain=np.sqrt(0.5)) if residual else self.conv1(x)
+        c0, c1 = self.conv0, self.conv1
+        g1 = np.sqrt(0.5) if residual else 1
+        if (conv_bias_act.first_order and x.device.type == 'cuda' and conv2d_gradfix.is_mixed(x, c0.weight) and c0.up == 1 and c0.down == 1 and c1.up == 1
+                and c1.down == 2 and c1.weight.shape[2] > 1 and conv_bias_act.fir_fusable(x, c0.weight, c0.activation, c1.resample_filter)):
+            # first-order passes: conv0 and the low-pass of conv1 as one Function, whose backward never writes the gradient w.r.t. conv0's output
+            x = c1(c0(x, then_lowpass_of=c1), gain=g1, prefiltered=True)
+        else:
+            x = c1(c0(x), gain=g1)
         if residual:
             x = shortcut + x     # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
         if self.attention is not None:

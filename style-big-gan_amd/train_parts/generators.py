@@ -210,18 +210,25 @@ class Conv2dLayer(torch.nn.Module):
             else:
                 self.bias = None
 
-    def forward(self, x, gain=1):
+    def forward(self, x, gain=1, prefiltered=False, then_lowpass_of=None):
+        """`then_lowpass_of` (a down-sampling Conv2dLayer that consumes the result next, with `prefiltered=True`): also apply THAT layer's low-pass, as one
+        first-order Function with this layer's convolution (ops/conv_bias_act.conv2d_bias_act_fir); the caller has checked fir_fusable"""
         b = self.bias               # fp32 as stored: the fused epilogue takes fp32, the unfused tail casts
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if then_lowpass_of is not None:
+            nxt = then_lowpass_of
+            assert self.up == 1 and self.down == 1 and nxt.up == 1 and nxt.down > 1
+            return conv_bias_act.conv2d_bias_act_fir(x, self.weight, b, nxt.resample_filter, conv2d_resample.lowpass_padding(nxt.resample_filter, nxt.down, nxt.padding),
+                                                     padding=self.padding, act=self.activation, gain=self.act_gain * gain, clamp=clamp, wgain=self.weight_gain)
         # conv2d_resample + bias_act (reference :179-184); the bias_act rides in the convolution kernel's epilogue when it can
         tail = dict(b=b, act=self.activation, alpha=None, gain=self.act_gain * gain, clamp=clamp)
         if conv2d_gradfix.is_mixed(x, self.weight) and x.device.type == 'cuda':
             # 16-bit block: hand the fp32 parameter over; `w * weight_gain`, the cast and the operand layout are one (cached) kernel
             return conv2d_resample.conv2d_resample(x=x, w=self.weight, f=self.resample_filter, up=self.up, down=self.down, padding=self.padding,
-                                                   flip_weight=(self.up == 1), bias_act_tail=tail, wgain=self.weight_gain)
+                                                   flip_weight=(self.up == 1), bias_act_tail=tail, wgain=self.weight_gain, prefiltered=prefiltered)
         w = self.weight * self.weight_gain
         return conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
-                                               padding=self.padding, flip_weight=(self.up == 1), bias_act_tail=tail)
+                                               padding=self.padding, flip_weight=(self.up == 1), bias_act_tail=tail, prefiltered=prefiltered)
 
 
 class MappingNetwork(torch.nn.Module):

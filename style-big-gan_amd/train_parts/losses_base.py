@@ -30,6 +30,7 @@ import torch
 
 from .. import utils
 from ..torch_utils import misc, training_stats
+from ..torch_utils.ops import conv_bias_act as _cba
 from ..torch_utils.ops import fromrgb as _fromrgb
 from ..utils import EasyDict
 from .losses import losses
@@ -41,6 +42,7 @@ _scope = torch.autograd.profiler.record_function
 
 import os as _os
 merge_d_passes = _os.environ.get('SBG_MERGE_D', '1') != '0'      # Dmain: one discriminator pass over [generated; real] (see _pass_d_adv)
+fuse_d_pairs = _os.environ.get('SBG_FUSE_D_PAIRS', '1') != '0'   # first-order D passes: conv0 + the low-pass of conv1 as one Function (ops/conv_bias_act.py)
 _order_cache = {}
 
 #             phase      passes, in execution order
@@ -108,11 +110,13 @@ class LossBase:
         rnd = _Round(real_img, real_c, gen_z, gen_c, sync, gain, segments)
         first_order_d = 'd_reg' not in passes
         fromrgb_was, _fromrgb.enabled = _fromrgb.enabled, first_order_d
+        pairs_was, _cba.first_order = _cba.first_order, first_order_d and fuse_d_pairs
         try:
             for k, name in enumerate(passes):
                 getattr(self, '_pass_' + name)(rnd, closes_round=(k == len(passes) - 1), reg_follows=('d_reg' in passes[k + 1:]))
         finally:
             _fromrgb.enabled = fromrgb_was
+            _cba.first_order = pairs_was
 
     # -- the four passes ---------------------------------------------------------------------------------------------------
     def _pass_g_adv(self, rnd, closes_round, reg_follows):

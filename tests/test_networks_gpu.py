@@ -143,3 +143,53 @@ def test_discriminator_with_streaming_fromrgb(dev):
             continue
         ec, ef = l2(gc, gr), l2(gf, gr)
         assert ef <= 1.5 * ec + 1e-2, (tuple(gr.shape), ec, ef)
+
+
+def test_discriminator_block_conv_lowpass_pair(dev):
+    """first-order discriminator passes run a block's conv0 and the low-pass of its down-sampling conv1 as ONE Function (ops/conv_bias_act.py
+    _ConvBiasActFir), whose backward takes the transposed low-pass, the activation gradient and the bias gradient from one launch
+    (sbg_upfirdn2d with a backward tail).  Same forward values as the composition; gradients (input, both weights, both biases) held to the
+    fp32 block as closely as the bf16 composition is -- for 'orig' and 'resnet' blocks, with and without clamp, at sizes with one and with
+    several vertical segments per strip, and a 129-column case whose forward low-pass splits off a ragged column."""
+    from style_big_gan_amd.torch_utils.ops import conv_bias_act
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for arch, res, cin, cout, clamp, n in (("orig", 32, 64, 128, 256, 3), ("resnet", 64, 64, 64, 0.7, 2), ("orig", 128, 64, 64, None, 1)):
+        torch.manual_seed(5)
+        kw = dict(in_channels=cin, tmp_channels=cin, out_channels=cout, resolution=res, img_channels=3, first_layer_idx=0, architecture=arch, conv_clamp=clamp)
+        B32 = PD.DiscriminatorBlock(use_fp16=False, **kw).to(dev)
+        B16 = PD.DiscriminatorBlock(use_fp16=True, **kw).to(dev)
+        B16.load_state_dict(B32.state_dict())
+        with torch.no_grad():
+            for p in B32.parameters():          # non-zero biases so that the clamp / slope masks are exercised on both sides
+                if p.ndim == 1:
+                    p.copy_(torch.randn_like(p) * 0.5)
+            B16.load_state_dict(B32.state_dict())
+        x0 = torch.randn(n, cin, res, res, device=dev)
+        dy = torch.randn(n, cout, res // 2, res // 2, device=dev)
+
+        def run(B, first_order):
+            x = x0.clone().requires_grad_(True)
+            conv_bias_act.first_order = first_order
+            try:
+                y, _ = B(x, None)
+                grads = torch.autograd.grad((y.float() * dy).sum(), [x] + list(B.parameters()))
+            finally:
+                conv_bias_act.first_order = False
+            return y.detach().float(), grads
+
+        ref, comp, fused = run(B32, False), run(B16, False), run(B16, True)
+        assert torch.equal(comp[0], fused[0]), (arch, res)                         # the forward launches are the same ones
+        assert l2(fused[0], ref[0]) < 2e-2
+        for gr, gc, gf in zip(ref[1], comp[1], fused[1]):
+            ec, ef = l2(gc, gr), l2(gf, gr)
+            assert ef <= 1.5 * ec + 5e-3, (arch, res, tuple(gr.shape), ec, ef)
+    # the fused Function refuses a second differentiation
+    B = PD.DiscriminatorBlock(in_channels=64, tmp_channels=64, out_channels=64, resolution=32, img_channels=3, first_layer_idx=0, architecture="orig", use_fp16=True).to(dev)
+    x = torch.randn(2, 64, 32, 32, device=dev, requires_grad=True)
+    conv_bias_act.first_order = True
+    try:
+        y, _ = B(x, None)
+    finally:
+        conv_bias_act.first_order = False
+    with pytest.raises(RuntimeError, match="first-order only"):
+        torch.autograd.grad(y.float().sum(), [x], create_graph=True)
