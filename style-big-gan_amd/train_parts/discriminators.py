@@ -299,9 +299,10 @@ class Discriminator(torch.nn.Module):
     def peak_activation_bytes(self):
         """bytes per sample of the largest tensor a forward pass creates (the low-passed input of a block's strided convolution,
         [tmp_channels, res + 1, res + 1]): what bounds the batch of one pass -- the op layer addresses tensors below 2^31 elements / 2 GiB
-        (the reference plugins' own limit, upfirdn2d.cpp:22-23)"""
+        (the reference plugins' own limit, upfirdn2d.cpp:22-23).  fp32 blocks count 12 bytes per element: their convolutions run on operands split into
+        bf16 parts and concatenated along the reduction axis (six parts of two bytes), and THAT tensor must stay below the limit for the fast kernels"""
         blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
-        return max(int(b.conv1.weight.shape[1]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 4) for b in blocks)
+        return max(int(b.conv1.weight.shape[1]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 12) for b in blocks)
 
     pass_bytes_limit = 1 << 31      # the op layer addresses tensors below 2 GiB (and, at two bytes per element, below 2^31 elements)
 
@@ -319,7 +320,7 @@ class Discriminator(torch.nn.Module):
 
     def _pass_plan(self, n):
         blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
-        peaks = [int(b.conv1.weight.shape[1]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 4) for b in blocks]
+        peaks = [int(b.conv1.weight.shape[1]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 12) for b in blocks]
         k = 0
         while k < len(peaks) and n * peaks[k] >= self.pass_bytes_limit:
             k += 1

@@ -568,7 +568,7 @@ class Generator(torch.nn.Module):
         """bytes per sample of the largest tensor a forward pass creates (the [C, res + 1, res + 1] output of an up-sampling convolution
         before its low-pass); see Discriminator.peak_activation_bytes"""
         blocks = [getattr(self.synthesis, f'b{res}') for res in self.synthesis.block_resolutions]
-        return max(int(b.conv1.weight.shape[0]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 4) for b in blocks)
+        return max(int(b.conv1.weight.shape[0]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 12) for b in blocks)
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
         ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
