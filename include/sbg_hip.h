@@ -215,6 +215,13 @@ int sbg_modconv_bwd_supported(int C);
 int sbg_modconv_bwd(const void* dy, const void* y, const float* dcoef, const float* noise, const float* bias,
                     void* d2, float* partial, float* dnoise, int dtype, int N, int C, int64_t HW, int64_t noise_stride_n,
                     int act, float alpha, float gain, float clamp, sbg_stream_t stream);
+/* Same, for a y that feeds a style-modulated convolution and nothing else (a synthesis block's conv0 output into its conv1, generators.py:462-463):
+ * `dy` is then the gradient w.r.t. y * prescale[n, c] (what that convolution's data gradient delivers); the pass also takes
+ * partial3[s][n*C + c] = sum_p dy * y (the gradient of prescale) and continues with dy * prescale -- autograd's `dy * s`, `(dy * x).sum([2, 3])` and the
+ * backward head above in one pass over (dy, y). */
+int sbg_modconv_bwd_prescaled(const void* dy, const void* y, const float* prescale, const float* dcoef, const float* noise, const float* bias,
+                              void* d2, float* partial, float* partial3, float* dnoise, int dtype, int N, int C, int64_t HW,
+                              int64_t noise_stride_n, int act, float alpha, float gain, float clamp, sbg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spectral norm, one power iteration with one singular vector (biggan/layers.py `power_iteration` :28-50, `SN.W_` :87-99):

@@ -133,6 +133,7 @@ SYMBOLS = [
     ("sbg_dot_hw_scale", _c.c_int, [_c.c_void_p] * 5 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_modconv_bwd_supported", _c.c_int, [_c.c_int]),
     ("sbg_modconv_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
+    ("sbg_modconv_bwd_prescaled", _c.c_int, [_c.c_void_p] * 10 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_void_p]),
     ("sbg_pack_weight", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int] + [_c.c_int64] * 4
      + [_c.c_int, _c.c_float, _c.c_void_p, _c.c_void_p]),
     ("sbg_unpack_wgrad", _c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p] + [_c.c_int] * 4

@@ -176,12 +176,17 @@ struct ModBwdArgs {
     void* d2; float* part; float* dnoise;
     int N, C; int64_t HW, nsn; int nsplit; int64_t pix_per_split;
     float alpha, gain, clamp;
+    // PRE: `dy` is the gradient w.r.t. y * prescale[n, c] (y feeds a style-modulated convolution and nothing else): the kernel takes
+    // sum_p dy * y (-> the gradient of prescale, part3[s][n][c]) and continues with dy * prescale -- the passes `dx = dy * s`, `sum dy * x` and this
+    // kernel's own over (dx, y) become one (sbg_modconv_bwd_prescaled)
+    const float* prescale; float* part3;
 };
 
-template <class T>
+template <class T, bool PRE>
 __global__ __launch_bounds__(256) void modconv_bwd_kernel(ModBwdArgs p)
 {
-    __shared__ float red[256 * 16];
+    constexpr int RW = PRE ? 24 : 16;                   // floats per thread in the reduction buffer
+    __shared__ float red[256 * RW];
     const T* pdy = (const T*)p.dy; const T* py = (const T*)p.y; T* pd2 = (T*)p.d2;
     const int n = blockIdx.x, s = blockIdx.y;
     const int cv = p.C >> 3;
@@ -189,10 +194,11 @@ __global__ __launch_bounds__(256) void modconv_bwd_kernel(ModBwdArgs p)
     int64_t p1 = p0 + p.pix_per_split; if (p1 > p.HW) p1 = p.HW;
     const int64_t base = (int64_t)n * p.HW * p.C;
     const int myc = threadIdx.x % cv, plane = threadIdx.x / cv, planes = 256 / cv;
-    float dc[8], bb[8], s1[8], s2[8];
+    float dc[8], bb[8], s1[8], s2[8], s3[8], ps[8];
     Vec8<float>::ld(p.dcoef + (int64_t)n * p.C + (myc << 3), dc);
 #pragma unroll
-    for (int j = 0; j < 8; j++) { bb[j] = p.bias ? p.bias[(myc << 3) + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    for (int j = 0; j < 8; j++) { bb[j] = p.bias ? p.bias[(myc << 3) + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; s3[j] = 0.f; ps[j] = 1.f; }
+    if (PRE) Vec8<float>::ld(p.prescale + (int64_t)n * p.C + (myc << 3), ps);
     const float inv_pos = 1.f / p.gain, inv_neg = p.alpha > 0.f ? 1.f / (p.gain * p.alpha) : 0.f;
     const float gpos = p.gain, gneg = p.gain * p.alpha;
     const float cl = p.clamp >= 0.f ? p.clamp : __builtin_inff();
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(256) void modconv_bwd_kernel(ModBwdArgs p)
             const float nz = p.noise ? p.noise[n * p.nsn + pix] : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
+                if (PRE) { s3[j] += g[j] * yv[j]; g[j] *= ps[j]; }
                 const bool pos = yv[j] > 0.f;
                 const bool live = (yv[j] > -cl) && (yv[j] < cl);
                 const float d1 = live ? g[j] * (pos ? gpos : gneg) : 0.f;
@@ -228,12 +235,12 @@ __global__ __launch_bounds__(256) void modconv_bwd_kernel(ModBwdArgs p)
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; j++) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
+    for (int j = 0; j < 8; j++) { red[threadIdx.x * RW + j] = s1[j]; red[threadIdx.x * RW + 8 + j] = s2[j]; if (PRE) red[threadIdx.x * RW + 16 + j] = s3[j]; }
     __syncthreads();
     for (int stride = planes >> 1; stride >= 1; stride >>= 1) {      // fixed-order tree over the pixel lanes
         if (plane < stride) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) red[threadIdx.x * 16 + j] += red[(threadIdx.x + stride * cv) * 16 + j];
+            for (int j = 0; j < RW; j++) red[threadIdx.x * RW + j] += red[(threadIdx.x + stride * cv) * RW + j];
         }
         __syncthreads();
     }
@@ -241,7 +248,12 @@ __global__ __launch_bounds__(256) void modconv_bwd_kernel(ModBwdArgs p)
         float* d0 = p.part + ((int64_t)s * p.N + n) * p.C + (myc << 3);
         float* d1p = d0 + (int64_t)p.nsplit * p.N * p.C;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { d0[j] = red[threadIdx.x * 16 + j]; d1p[j] = red[threadIdx.x * 16 + 8 + j]; }
+        for (int j = 0; j < 8; j++) { d0[j] = red[threadIdx.x * RW + j]; d1p[j] = red[threadIdx.x * RW + 8 + j]; }
+        if (PRE) {
+            float* d3 = p.part3 + ((int64_t)s * p.N + n) * p.C + (myc << 3);
+#pragma unroll
+            for (int j = 0; j < 8; j++) d3[j] = red[threadIdx.x * RW + 16 + j];
+        }
     }
 }
 
@@ -375,9 +387,28 @@ extern "C" int sbg_modconv_bwd_supported(int C)
     return (C % 8) == 0 && cv >= 1 && cv <= 64 && (cv & (cv - 1)) == 0;
 }
 
+static int modconv_bwd_impl(const void* dy, const void* y, const float* prescale, const float* dcoef, const float* noise, const float* bias,
+                            void* d2, float* partial, float* partial3, float* dnoise, int dtype, int N, int C, int64_t HW, int64_t noise_stride_n,
+                            int act, float alpha, float gain, float clamp, sbg_stream_t stream);
+
 extern "C" int sbg_modconv_bwd(const void* dy, const void* y, const float* dcoef, const float* noise, const float* bias,
                                void* d2, float* partial, float* dnoise, int dtype, int N, int C, int64_t HW, int64_t noise_stride_n,
                                int act, float alpha, float gain, float clamp, sbg_stream_t stream)
+{
+    return modconv_bwd_impl(dy, y, nullptr, dcoef, noise, bias, d2, partial, nullptr, dnoise, dtype, N, C, HW, noise_stride_n, act, alpha, gain, clamp, stream);
+}
+
+extern "C" int sbg_modconv_bwd_prescaled(const void* dy, const void* y, const float* prescale, const float* dcoef, const float* noise, const float* bias,
+                                         void* d2, float* partial, float* partial3, float* dnoise, int dtype, int N, int C, int64_t HW,
+                                         int64_t noise_stride_n, int act, float alpha, float gain, float clamp, sbg_stream_t stream)
+{
+    SBG_CHECK(prescale && partial3 && sbg_aligned16(prescale), "modconv_bwd_prescaled: prescale (16-byte aligned) and partial3 are required");
+    return modconv_bwd_impl(dy, y, prescale, dcoef, noise, bias, d2, partial, partial3, dnoise, dtype, N, C, HW, noise_stride_n, act, alpha, gain, clamp, stream);
+}
+
+static int modconv_bwd_impl(const void* dy, const void* y, const float* prescale, const float* dcoef, const float* noise, const float* bias,
+                            void* d2, float* partial, float* partial3, float* dnoise, int dtype, int N, int C, int64_t HW, int64_t noise_stride_n,
+                            int act, float alpha, float gain, float clamp, sbg_stream_t stream)
 {
     SBG_CHECK(dy && y && dcoef && d2 && partial, "modconv_bwd: null pointer");
     SBG_CHECK(dtype == SBG_F16 || dtype == SBG_BF16 || dtype == SBG_F32, "modconv_bwd: unsupported dtype %d", dtype);
@@ -387,16 +418,23 @@ extern "C" int sbg_modconv_bwd(const void* dy, const void* y, const float* dcoef
     SBG_CHECK(sbg_aligned16(dy) && sbg_aligned16(y) && sbg_aligned16(d2) && sbg_aligned16(dcoef), "modconv_bwd: tensors must be 16-byte aligned");
     ModBwdArgs p;
     p.dy = dy; p.y = y; p.dcoef = dcoef; p.noise = noise; p.bias = bias; p.d2 = d2; p.part = partial; p.dnoise = dnoise;
+    p.prescale = prescale; p.part3 = partial3;
     p.N = N; p.C = C; p.HW = HW; p.nsn = noise_stride_n;
     p.nsplit = sbg_dot_hw_splits(1, N, C, HW);
     p.pix_per_split = (HW + p.nsplit - 1) / p.nsplit;
     p.alpha = act == SBG_ACT_LRELU ? alpha : (act == SBG_ACT_RELU ? 0.f : 1.f); p.gain = gain; p.clamp = clamp;
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype == SBG_F32 ? 4 : 2;
-    SbgProfScope prof(s, SBG_K_DOT_HW, 0.0, 3.0 * es * N * (double)C * HW, {N, C, (int)HW, 2});
-    if (dtype == SBG_F32)      SBG_LAUNCH((modconv_bwd_kernel<float>), dim3(N, p.nsplit), dim3(256), 0, s, p);
-    else if (dtype == SBG_F16) SBG_LAUNCH((modconv_bwd_kernel<f16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
-    else                       SBG_LAUNCH((modconv_bwd_kernel<bf16_s>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    SbgProfScope prof(s, SBG_K_DOT_HW, 0.0, 3.0 * es * N * (double)C * HW, {N, C, (int)HW, prescale ? 4 : 2});
+    if (prescale) {
+        if (dtype == SBG_F32)      SBG_LAUNCH((modconv_bwd_kernel<float, true>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+        else if (dtype == SBG_F16) SBG_LAUNCH((modconv_bwd_kernel<f16_s, true>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+        else                       SBG_LAUNCH((modconv_bwd_kernel<bf16_s, true>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    } else {
+        if (dtype == SBG_F32)      SBG_LAUNCH((modconv_bwd_kernel<float, false>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+        else if (dtype == SBG_F16) SBG_LAUNCH((modconv_bwd_kernel<f16_s, false>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+        else                       SBG_LAUNCH((modconv_bwd_kernel<bf16_s, false>), dim3(N, p.nsplit), dim3(256), 0, s, p);
+    }
     SBG_HIP_LAUNCH_CHECK();
     return SBG_OK;
 }

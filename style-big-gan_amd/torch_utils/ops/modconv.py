@@ -16,8 +16,11 @@ from ... import _lib
 from . import bias_act as _ba
 from . import conv2d_gradfix as _cg
 from . import modulate as _mod
+from . import upfirdn2d as _up
 
 enabled = True      # module switch: False -> SynthesisLayer uses modulated_conv2d + bias_act (arbitrarily differentiable)
+import os as _os
+chain_heads = _os.environ.get("SBG_CHAIN_HEADS", "1") != "0"       # a layer's backward also runs the backward head of the layer that feeds it (x_sole_consumer)
 
 _ACT = {"linear": 1, "relu": 2, "lrelu": 3}
 
@@ -31,7 +34,8 @@ class _ModConvBiasAct(torch.autograd.Function):
     """y = clamp(act(conv(x * s, w) * dcoefs + noise + b) * gain);  cfg = (padding, act, alpha, gain, clamp)"""
 
     @staticmethod
-    def forward(ctx, x, w, styles, dcoefs, noise, b, cfg):
+    def forward(ctx, x, w, styles, dcoefs, noise, b, cfg, x_tail=None):
+        ctx.x_tail = x_tail          # upfirdn2d.TailHandle of the layer that produced x, when this layer is x's ONLY consumer (see backward)
         padding, act, alpha, gain, clamp = cfg
         xs = _mod._scale_nc_launch(x, styles, None)
         epi = _cg.Epilogue(oscale=dcoefs, noise=noise, bias=b, act=act, alpha=alpha, gain=gain, clamp=clamp)
@@ -47,26 +51,9 @@ class _ModConvBiasAct(torch.autograd.Function):
         if torch.is_grad_enabled():
             raise RuntimeError("modconv: the fused layer is first-order only; set torch_utils.ops.modconv.enabled = False "
                                "before building a graph that is differentiated twice (path-length regularisation)")
-        lib = _lib.load()
         n, cout, h, wd = y.shape
-        dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
-        dc32 = dcoefs.detach().to(torch.float32).reshape(n, cout).contiguous()
-        nz = nsn = None
-        if noise is not None:
-            nz = noise.detach().to(torch.float32)
-            per_sample = nz.numel() != h * wd
-            nz = nz.reshape(n if per_sample else 1, h * wd).contiguous()
-            nsn = h * wd if per_sample else 0
-        b32 = b.detach().to(torch.float32).contiguous() if b is not None else None
-        ns = lib.sbg_dot_hw_splits(1, n, cout, h * wd)
-        part = torch.empty([2, ns, n, cout], dtype=torch.float32, device=y.device)
-        d2 = torch.empty_like(y)
         want_dn = noise is not None and ctx.needs_input_grad[4]
-        dn = torch.empty([n, 1, h, wd], dtype=torch.float32, device=y.device) if want_dn else None
-        _lib.check(lib.sbg_modconv_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dc32), _lib.ptr(nz), _lib.ptr(b32), _lib.ptr(d2), _lib.ptr(part),
-                                       _lib.ptr(dn), _lib.dtype_code(y.dtype), n, cout, h * wd, nsn or 0, _ACT[act], float(alpha), float(gain),
-                                       float(clamp), _lib.stream_ptr(y.device)), "sbg_modconv_bwd")
-        sums = part.sum(1)                                   # [2, N, Cout], fixed order
+        d2, sums, dn, dc32 = _up.backward_head(dy, y, dcoefs, noise, b, act, alpha, gain, clamp, want_dn)      # [2, N, Cout] sums, fixed order
         dx = dw = dstyles = ddcoefs = dnoise = db = None
         if ctx.needs_input_grad[3]:
             ddcoefs = (sums[1] / dc32).to(dcoefs.dtype).reshape(dcoefs.shape)
@@ -78,17 +65,30 @@ class _ModConvBiasAct(torch.autograd.Function):
         ccfg = (False, (1, 1), (padding, padding), (0, 0))
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             dxs = _cg._Conv.apply(d2, w, (True, (1, 1), (padding, padding), (0, 0)))
-            both = _mod._dot_hw_scale_launch(dxs, x, styles) if (ctx.needs_input_grad[0] and ctx.needs_input_grad[2]) else None
-            if both is not None:                             # dx = dxs * s and sum_hw dxs * x from one pass over (dxs, x)
-                dx, dstyles = both[0], both[1].to(styles.dtype).reshape(styles.shape)
+            tail = ctx.x_tail
+            both = None
+            if (tail is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and dxs.dtype == x.dtype
+                    and _lib.load().sbg_modconv_bwd_supported(x.shape[1])):
+                # x = clamp(act(...)) is the output of an up-sampling layer's fused tail and feeds nothing but this convolution: `dxs * s`, `sum dxs * x`
+                # and THAT layer's backward head (activation slope at x, bias / demodulation / noise sums) are one pass over (dxs, x).  What goes back
+                # as "the gradient of x" is already the gradient of that layer's pre-activation; its backward recognises the tensor (TailHandle).
+                hd2, hsums, hdn, hdc32, dst = _up.backward_head(dxs, x, tail.dcoefs, tail.noise, tail.b, tail.act, tail.alpha, tail.act_gain, tail.clamp,
+                                                                tail.noise is not None, prescale=styles)
+                tail.result = dict(ptr=hd2.data_ptr(), sums=hsums, dn=hdn, dc32=hdc32)
+                dx, dstyles = hd2, dst.to(styles.dtype).reshape(styles.shape)
             else:
-                if ctx.needs_input_grad[0]:
-                    dx = _mod._scale_nc_launch(dxs, styles, None)
-                if ctx.needs_input_grad[2]:
-                    dstyles = _mod._dot_hw_launch(dxs, x).to(styles.dtype).reshape(styles.shape)
+                if ctx.needs_input_grad[0] and ctx.needs_input_grad[2]:
+                    both = _mod._dot_hw_scale_launch(dxs, x, styles)
+                if both is not None:                         # dx = dxs * s and sum_hw dxs * x from one pass over (dxs, x)
+                    dx, dstyles = both[0], both[1].to(styles.dtype).reshape(styles.shape)
+                else:
+                    if ctx.needs_input_grad[0]:
+                        dx = _mod._scale_nc_launch(dxs, styles, None)
+                    if ctx.needs_input_grad[2]:
+                        dstyles = _mod._dot_hw_launch(dxs, x).to(styles.dtype).reshape(styles.shape)
         if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
             dw = _cg._ConvWgrad.apply(d2, xs, ccfg, tuple(w.shape), _cg.wmeta_of(xs, w))
-        return dx, dw, dstyles, ddcoefs, dnoise, db, None
+        return dx, dw, dstyles, ddcoefs, dnoise, db, None, None
 
 
 class _DemodCoefs(torch.autograd.Function):
@@ -132,10 +132,13 @@ def demod_coefs(weight, styles, act_dtype):
     return _DemodCoefs.apply(weight, styles, act_dtype)
 
 
-def modconv_bias_act(x, weight, styles, dcoefs, noise, bias, padding, act="lrelu", alpha=None, gain=None, clamp=None):
+def modconv_bias_act(x, weight, styles, dcoefs, noise, bias, padding, act="lrelu", alpha=None, gain=None, clamp=None, x_sole_consumer=False):
     """Fused SynthesisLayer body (up = 1): x [N, Cin, H, W] 16-bit, weight [Cout, Cin, k, k] same dtype or the fp32 parameter, styles [N, Cin],
-    dcoefs [N, Cout] (demodulation coefficients, differentiable), noise None / [N, 1, H, W] / [H, W], bias [Cout]."""
+    dcoefs [N, Cout] (demodulation coefficients, differentiable), noise None / [N, 1, H, W] / [H, W], bias [Cout].
+    `x_sole_consumer`: the caller guarantees that nothing else reads x; if x is the output of upfirdn2d.fir_bias_act (an up-sampling layer's fused tail),
+    this layer's backward then also runs that layer's backward head, in the same pass as its own input gradients."""
     spec = _ba.activation_funcs[act]
     cfg = (int(padding), act, float(alpha if alpha is not None else spec.def_alpha), float(gain if gain is not None else spec.def_gain),
            float(clamp if clamp is not None else -1))
-    return _ModConvBiasAct.apply(x, weight, styles, dcoefs, noise, bias, cfg)
+    x_tail = getattr(x, "_sbg_tail", None) if (x_sole_consumer and chain_heads) else None
+    return _ModConvBiasAct.apply(x, weight, styles, dcoefs, noise, bias, cfg, x_tail)

@@ -248,6 +248,50 @@ class _Upfirdn2d(torch.autograd.Function):
         return dx, None, None
 
 
+class TailHandle:
+    """What the sole consumer of a fir_bias_act output needs in order to run THAT layer's backward head itself, fused with its own input
+    gradients (ops/modconv.py: `dx = dxs * s`, `sum dxs * x` and the head below are three passes over the same two tensors), and the slot through
+    which it hands the result back to _FirBiasAct.backward."""
+    __slots__ = ("dcoefs", "noise", "b", "act", "alpha", "act_gain", "clamp", "result")
+
+    def __init__(self, dcoefs, noise, b, act, alpha, act_gain, clamp):
+        self.dcoefs, self.noise, self.b, self.act, self.alpha, self.act_gain, self.clamp = dcoefs, noise, b, act, alpha, act_gain, clamp
+        self.result = None
+
+
+def backward_head(dy, y, dcoefs, noise, b, act, alpha, act_gain, clamp, want_dn, prescale=None):
+    """one pass over (dy, y) for y = clamp(act(c * dcoefs + noise + b) * act_gain): (d2 = gradient w.r.t. c, sums [2, N, C] = bias / demodulation
+    partial sums, dn = per-pixel noise gradient or None, dc32) -- sbg_modconv_bwd.  With `prescale` [N, C]: dy is the gradient w.r.t. y * prescale; also
+    returns sum_hw dy * y (the gradient of prescale) as a fifth value -- sbg_modconv_bwd_prescaled."""
+    lib = _lib.load()
+    n, c, oh, ow = y.shape
+    dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
+    dc32 = (dcoefs.detach().to(torch.float32).reshape(n, c) if dcoefs is not None else torch.ones([n, c], dtype=torch.float32, device=y.device)).contiguous()
+    nz = nsn = None
+    if noise is not None:
+        nz = noise.detach().to(torch.float32)
+        per_sample = nz.numel() != oh * ow
+        nz = nz.reshape(n if per_sample else 1, oh * ow).contiguous()
+        nsn = oh * ow if per_sample else 0
+    b32 = b.detach().to(torch.float32).contiguous() if b is not None else None
+    ns = lib.sbg_dot_hw_splits(1, n, c, oh * ow)
+    part = torch.empty([2, ns, n, c], dtype=torch.float32, device=y.device)
+    d2 = torch.empty_like(y)
+    dn = torch.empty([n, 1, oh, ow], dtype=torch.float32, device=y.device) if want_dn else None
+    code = {"linear": 1, "relu": 2, "lrelu": 3}[act]
+    if prescale is None:
+        _lib.check(lib.sbg_modconv_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dc32), _lib.ptr(nz), _lib.ptr(b32), _lib.ptr(d2), _lib.ptr(part),
+                                       _lib.ptr(dn), _lib.dtype_code(y.dtype), n, c, oh * ow, nsn or 0, code,
+                                       float(alpha), float(act_gain), float(clamp), _lib.stream_ptr(y.device)), "sbg_modconv_bwd")
+        return d2, part.sum(1), dn, dc32
+    ps32 = prescale.detach().to(torch.float32).reshape(n, c).contiguous()
+    part3 = torch.empty([ns, n, c], dtype=torch.float32, device=y.device)
+    _lib.check(lib.sbg_modconv_bwd_prescaled(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(ps32), _lib.ptr(dc32), _lib.ptr(nz), _lib.ptr(b32), _lib.ptr(d2),
+                                             _lib.ptr(part), _lib.ptr(part3), _lib.ptr(dn), _lib.dtype_code(y.dtype), n, c, oh * ow, nsn or 0, code,
+                                             float(alpha), float(act_gain), float(clamp), _lib.stream_ptr(y.device)), "sbg_modconv_bwd_prescaled")
+    return d2, part.sum(1), dn, dc32, part3.sum(0)
+
+
 class _FirBiasAct(torch.autograd.Function):
     """y = clamp(act(upfirdn2d(t, f, padding, gain) * dcoefs[n, c] + noise + b) * act_gain) in one kernel (up = down = 1; the low-pass after
     the transposed convolution of an up-sampling synthesis layer with the layer's whole tail, generators.py:84-88,328).  Backward: one pass
@@ -255,12 +299,12 @@ class _FirBiasAct(torch.autograd.Function):
     transposed FIR.  First order only (see ops/modconv.py).   cfg = (padx0, padx1, pady0, pady1, flip, gain, act, alpha, act_gain, clamp)"""
 
     @staticmethod
-    def forward(ctx, t, f, dcoefs, noise, b, cfg):
+    def forward(ctx, t, f, dcoefs, noise, b, cfg, handle):
         padx0, padx1, pady0, pady1, flip, gain, act, alpha, act_gain, clamp = cfg
         y = _launch(t, f, 1, 1, 1, 1, padx0, padx1, pady0, pady1, flip, gain,
                     tail=dict(oscale=dcoefs, noise=noise, bias=b, act=act, alpha=alpha, gain=act_gain, clamp=clamp))
         ctx.save_for_backward(f, dcoefs, noise, b, y)
-        ctx.cfg, ctx.in_hw = cfg, (t.shape[2], t.shape[3])
+        ctx.cfg, ctx.in_hw, ctx.handle = cfg, (t.shape[2], t.shape[3]), handle
         return y
 
     @staticmethod
@@ -269,26 +313,18 @@ class _FirBiasAct(torch.autograd.Function):
         padx0, padx1, pady0, pady1, flip, gain, act, alpha, act_gain, clamp = ctx.cfg
         if torch.is_grad_enabled():
             raise RuntimeError("fir_bias_act: first-order only; set torch_utils.ops.modconv.enabled = False for double backward")
-        lib = _lib.load()
         n, c, oh, ow = y.shape
-        dy = dy.to(y.dtype).contiguous(memory_format=torch.channels_last)
-        dc32 = (dcoefs.detach().to(torch.float32).reshape(n, c) if dcoefs is not None else torch.ones([n, c], dtype=torch.float32, device=y.device)).contiguous()
-        nz = nsn = None
-        if noise is not None:
-            nz = noise.detach().to(torch.float32)
-            per_sample = nz.numel() != oh * ow
-            nz = nz.reshape(n if per_sample else 1, oh * ow).contiguous()
-            nsn = oh * ow if per_sample else 0
-        b32 = b.detach().to(torch.float32).contiguous() if b is not None else None
-        ns = lib.sbg_dot_hw_splits(1, n, c, oh * ow)
-        part = torch.empty([2, ns, n, c], dtype=torch.float32, device=y.device)
-        d2 = torch.empty_like(y)
         want_dn = noise is not None and ctx.needs_input_grad[3]
-        dn = torch.empty([n, 1, oh, ow], dtype=torch.float32, device=y.device) if want_dn else None
-        _lib.check(lib.sbg_modconv_bwd(_lib.ptr(dy), _lib.ptr(y), _lib.ptr(dc32), _lib.ptr(nz), _lib.ptr(b32), _lib.ptr(d2), _lib.ptr(part),
-                                       _lib.ptr(dn), _lib.dtype_code(y.dtype), n, c, oh * ow, nsn or 0, {"linear": 1, "relu": 2, "lrelu": 3}[act],
-                                       float(alpha), float(act_gain), float(clamp), _lib.stream_ptr(y.device)), "sbg_modconv_bwd")
-        sums = part.sum(1)
+        handed = ctx.handle.result if ctx.handle is not None else None
+        if handed is not None:      # the consumer of y ran this head together with its own input gradients (ops/modconv.py): dy IS d2
+            ctx.handle.result = None
+            if handed["ptr"] != dy.data_ptr() or dy.shape != y.shape:
+                raise RuntimeError("fir_bias_act: the consumer handed over a backward head, but the incoming gradient is another tensor -- "
+                                   "the output must have exactly that one consumer (TailHandle)")
+            d2, sums, dn, dc32 = dy, handed["sums"], handed["dn"], handed["dc32"]
+            want_dn = want_dn and dn is not None
+        else:
+            d2, sums, dn, dc32 = backward_head(dy, y, dcoefs, noise, b, act, alpha, act_gain, clamp, want_dn)
         dt = ddc = dnoise = db = None
         if dcoefs is not None and ctx.needs_input_grad[2]:
             ddc = (sums[1] / dc32).to(dcoefs.dtype).reshape(dcoefs.shape)
@@ -301,7 +337,7 @@ class _FirBiasAct(torch.autograd.Function):
             fw, fh = _get_filter_size(f)
             gcfg = (1, 1, 1, 1, fw - padx0 - 1, iw - ow + padx0, fh - pady0 - 1, ih - oh + pady0, not flip, gain)
             dt = _Upfirdn2d.apply(d2, f, gcfg)
-        return dt, None, ddc, dnoise, db, None
+        return dt, None, ddc, dnoise, db, None, None
 
 
 def fir_transposed_dact(dy, f, cfg, in_hw, y_saved, act, alpha, gain, clamp):
@@ -330,7 +366,10 @@ def fir_tail_supported(x, f, padding, flip_filter=False):
 def fir_bias_act(x, f, padding, gain, dcoefs, noise, b, act="lrelu", alpha=0.2, act_gain=1.0, clamp=-1.0, flip_filter=False):
     padx0, padx1, pady0, pady1 = _parse_padding(padding)
     cfg = (padx0, padx1, pady0, pady1, bool(flip_filter), float(gain), act, float(alpha), float(act_gain), float(clamp))
-    return _FirBiasAct.apply(x, f, dcoefs, noise, b, cfg)
+    handle = TailHandle(dcoefs, noise, b, act, float(alpha), float(act_gain), float(clamp))
+    y = _FirBiasAct.apply(x, f, dcoefs, noise, b, cfg, handle)
+    y._sbg_tail = handle        # a consumer that KNOWS it is the only one may take over this layer's backward head (ops/modconv.py, x_tail)
+    return y
 
 
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="cuda"):

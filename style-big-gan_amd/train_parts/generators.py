@@ -324,7 +324,9 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, x_sole_consumer=False):
+        """`x_sole_consumer` (extension): the caller guarantees that this layer is the only reader of x (a block's conv1 after its conv0), which lets
+        the fused training path chain the two layers' backward heads (ops/modconv.modconv_bias_act)"""
         assert noise_mode in ['random', 'const', 'none']
         misc.assert_shape(x, [None, self.weight.shape[1], self.resolution // self.up, self.resolution // self.up])
         styles = self.affine(w)
@@ -349,7 +351,8 @@ class SynthesisLayer(torch.nn.Module):
         if modconv.usable(x, self.weight, self.activation, self.up):
             # training pass, first order: same fused epilogue, plus a one-pass backward head (torch_utils/ops/modconv.py)
             return modconv.modconv_bias_act(x, self.weight, styles, demod_coefficients(self.weight, styles, x.dtype), noise, self.bias,
-                                            padding=self.padding, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+                                            padding=self.padding, act=self.activation, gain=self.act_gain * gain, clamp=clamp,
+                                            x_sole_consumer=x_sole_consumer)
         if (self.up == 2 and modconv.enabled and x.device.type == 'cuda' and x.dtype == torch.bfloat16
                 and self.activation in ('linear', 'relu', 'lrelu')):
             # up-sampling layer, first-order training pass: x * s -> transposed convolution (one multi-phase launch) -> low-pass whose kernel
@@ -467,7 +470,8 @@ class SynthesisBlock(torch.nn.Module):
         shortcut = self.skip(x, gain=np.sqrt(0.5)) if residual else None
         if not first:
             x = self.conv0(x, next(w_iter), **lk)
-        x = self.conv1(x, next(w_iter), gain=np.sqrt(0.5), **lk) if residual else self.conv1(x, next(w_iter), **lk)
+        sole = not first        # conv0's output is read by conv1 and by nothing else
+        x = self.conv1(x, next(w_iter), gain=np.sqrt(0.5), x_sole_consumer=sole, **lk) if residual else self.conv1(x, next(w_iter), x_sole_consumer=sole, **lk)
         if residual:
             x = shortcut + x     # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
         if self.attention is not None:

@@ -245,7 +245,8 @@ def test_rounds_in_one_pass_equal_separate_rounds(dev):
         for name in gb:
             assert len(ga[name]) == len(gb[name]) > 0
             for a, b in zip(ga[name], gb[name]):
-                assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-7, (nfp, name, tuple(b.shape), float((a - b).abs().max()), float(b.abs().max()))
+                # (absolute floor: R1's gradient w.r.t. a bias of a piecewise-linear network is zero up to rounding -- such tensors are ~1e-7 of noise)
+                assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-6, (nfp, name, tuple(b.shape), float((a - b).abs().max()), float(b.abs().max()))
 
     gk2, dk2 = _sg2_kwargs(res=32, attn_g=(16,))                         # power iterations in G's attention block: rounds stay apart
     eng = trainers.StepEngine(dev, seed=5, gen_kwargs=gk2, disc_kwargs=dk2, loss_arch_kwargs=dict(style_mixing_prob=0), batch=16, batch_gpu=8)

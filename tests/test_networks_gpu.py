@@ -193,3 +193,51 @@ def test_discriminator_block_conv_lowpass_pair(dev):
         conv_bias_act.first_order = False
     with pytest.raises(RuntimeError, match="first-order only"):
         torch.autograd.grad(y.float().sum(), [x], create_graph=True)
+
+
+def test_synthesis_block_chained_backward_heads(dev):
+    """In a synthesis block the up-sampling conv0's output (the fused tail of its low-pass) feeds conv1 and nothing else, so conv1's backward runs
+    conv0's backward head in the same pass as its own input gradients (ops/modconv.py x_sole_consumer -> sbg_modconv_bwd_prescaled; the unchained
+    path: `dxs * s`, `sum dxs * x`, then conv0's head over the same tensors).  Same forward; every gradient (x, ws, both layers' weights, biases,
+    noise strengths, affine layers, ToRGB) held to the fp32 block as closely as the unchained bf16 path is; per-sample noise and constant noise."""
+    from style_big_gan_amd.torch_utils.ops import modconv
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for arch, res, cin, cout, noise_mode, n in (("skip", 32, 128, 64, "random", 3), ("resnet", 64, 64, 64, "const", 2)):
+        torch.manual_seed(6)
+        kw = dict(in_channels=cin, out_channels=cout, w_dim=48, resolution=res, img_channels=3, is_last=False, architecture=arch, conv_clamp=256)
+        B32 = PG.SynthesisBlock(use_fp16=False, **kw).to(dev)
+        B16 = PG.SynthesisBlock(use_fp16=True, **kw).to(dev)
+        with torch.no_grad():
+            for name, p in B32.named_parameters():
+                if name.endswith("noise_strength"):
+                    p.fill_(0.3)
+                elif name.endswith("bias") and "affine" not in name:
+                    p.copy_(torch.randn_like(p) * 0.3)
+        B16.load_state_dict(B32.state_dict())
+        x0 = torch.randn(n, cin, res // 2, res // 2, device=dev)
+        img0 = torch.randn(n, 3, res // 2, res // 2, device=dev) if arch == "skip" else None
+        ws0 = torch.randn(n, B32.num_conv + B32.num_torgb, 48, device=dev)
+        dx_out = torch.randn(n, cout, res, res, device=dev)
+
+        def run(B, chain):
+            x = x0.clone().requires_grad_(True); ws = ws0.clone().requires_grad_(True)
+            was, modconv.chain_heads = modconv.chain_heads, chain
+            try:
+                torch.manual_seed(123)                                              # the same per-layer noise draws in every run
+                y, img = B(x, None if img0 is None else img0.clone(), ws, noise_mode=noise_mode)
+                loss = (y.float() * dx_out).sum() + (img.float().square().sum() if img is not None else 0)
+                grads = torch.autograd.grad(loss, [x, ws] + list(B.parameters()), allow_unused=True)
+            finally:
+                modconv.chain_heads = was
+            return y.detach().float(), grads
+
+        ref, plain, chained = run(B32, False), run(B16, False), run(B16, True)
+        assert torch.equal(plain[0], chained[0]), (arch, res)
+        assert l2(chained[0], ref[0]) < 2e-2
+        names = ["x", "ws"] + [k for k, _ in B16.named_parameters()]
+        for name, gr, gp, gc in zip(names, ref[1], plain[1], chained[1]):
+            if gr is None:
+                assert gp is None and gc is None, name
+                continue
+            ep, ec = l2(gp, gr), l2(gc, gr)
+            assert ec <= 1.5 * ep + 5e-3, (arch, res, name, ep, ec)
