@@ -42,6 +42,31 @@ __global__ void __launch_bounds__(256) pack_weight_kernel(PackArgs p)
     }
 }
 
+// The same packing when the SOURCE is contiguous along the rows a (stride 1) and far-strided along the columns b -- the data-gradient operand
+// [tap][Cin][Cout] of a channel-minor parameter [Cout][kh][kw][Cin]: with one lane per (a, b) pair the reads above are 4 bytes at an 18 KB stride.
+// 32 x 32 tiles go through LDS instead: reads run along a, writes along b.  grid = (A / 32, Bp / 32, taps).
+template <class T>
+__global__ void __launch_bounds__(256) pack_weight_t_kernel(PackArgs p)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32, t = blockIdx.z;
+    const int kh = t / p.KW, kw = t - kh * p.KW;
+    const float* src = p.w + (int64_t)kh * p.sKH + (int64_t)kw * p.sKW;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int a = a0 + tx, b = b0 + ty + 8 * r;
+        tile[ty + 8 * r][tx] = (a < p.A && b < p.B) ? src[(int64_t)a * p.sA + (int64_t)b * p.sB] * p.gain : 0.0f;
+    }
+    __syncthreads();
+    T* out = (T*)p.out + (int64_t)t * p.A * p.Bp;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int a = a0 + ty + 8 * r, b = b0 + tx;
+        if (a < p.A && b < p.Bp) Elem<T>::st(out + (int64_t)a * p.Bp + b, tile[tx][ty + 8 * r]);
+    }
+}
+
 struct UnpackArgs {
     const float* dwp; float* dw; const float* w; const float* dw2;
     int A, B, KH, KW;
@@ -82,6 +107,15 @@ extern "C" int sbg_pack_weight(const float* w, void* out, int out_dtype, int A, 
     const int64_t total = (int64_t)A * Bp;
     SbgProfScope prof(stream, SBG_K_WEIGHT_PREP, 0.0, (double)A * B * KH * KW * (4.0 + sbg_dtype_size(out_dtype)), {A, B, KH * KW, 0, 0, 0, 0});
     dim3 grid(sbg_stream_grid(total, 256)), block(256);
+    if (!w2 && sA == 1 && sB >= 64 && A >= 32 && B >= 32 && KH * KW <= 65535) {       // transposing form (see pack_weight_t_kernel)
+        const dim3 tgrid((unsigned)((A + 31) / 32), (unsigned)((Bp + 31) / 32), (unsigned)(KH * KW));
+        if (out_dtype == SBG_BF16)      SBG_LAUNCH(pack_weight_t_kernel<bf16_s>, tgrid, block, 0, stream, a);
+        else if (out_dtype == SBG_F16)  SBG_LAUNCH(pack_weight_t_kernel<f16_s>, tgrid, block, 0, stream, a);
+        else if (out_dtype == SBG_F32)  SBG_LAUNCH(pack_weight_t_kernel<float>, tgrid, block, 0, stream, a);
+        else return sbg_fail(SBG_ERR_INVALID, "pack_weight: bad dtype %d", out_dtype);
+        SBG_HIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (out_dtype == SBG_BF16)      SBG_LAUNCH(pack_weight_kernel<bf16_s>, grid, block, 0, stream, a);
     else if (out_dtype == SBG_F16)  SBG_LAUNCH(pack_weight_kernel<f16_s>, grid, block, 0, stream, a);
     else if (out_dtype == SBG_F32)  SBG_LAUNCH(pack_weight_kernel<float>, grid, block, 0, stream, a);
