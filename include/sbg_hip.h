@@ -87,6 +87,9 @@ typedef struct sbg_upfirdn2d_params {
      * gradient: dact_partial[r][64] for r < sbg_upfirdn2d_dact_rows(), row r = ((n * ysegs + s) * xstrips + x) * (C / 64) + channel block, to be summed
      * over everything but the channel block by the caller.  Sliding-window matrix-core FIR only: _dact_rows() returns -1 for other launches. */
     const void* dact_y; float* dact_partial; int dact_act; float dact_alpha, dact_gain, dact_clamp;
+    /* Forward tail only: the finished value is multiplied by post_scale[n*C + c] -- the style modulation `x * styles` of the layer that reads this
+     * output next (generators.py:79), for passes in which nothing else reads it (inference-mode generator passes).  NULL = none. */
+    const float* post_scale;
 } sbg_upfirdn2d_params;
 int sbg_upfirdn2d_tail_supported(const sbg_upfirdn2d_params* p);
 int64_t sbg_upfirdn2d_dact_rows(const sbg_upfirdn2d_params* p);

@@ -39,6 +39,7 @@ class UpfirdnParams(ctypes.Structure):
         ("filter_exact16", ctypes.c_int),
         ("dact_y", ctypes.c_void_p), ("dact_partial", ctypes.c_void_p), ("dact_act", ctypes.c_int),
         ("dact_alpha", ctypes.c_float), ("dact_gain", ctypes.c_float), ("dact_clamp", ctypes.c_float),
+        ("post_scale", ctypes.c_void_p),
     ]
 
 

@@ -32,6 +32,7 @@ struct UpfirdnArgs {
     // same geometry as this launch's output); the kernel multiplies by the activation's slope at y -- dact_gpos for y > 0, dact_gneg below, zero on the
     // clamp rails |y| >= dact_rail -- and adds up the result per channel (the bias gradient): dact_part[workgroup][64]
     const void* dact_y; float* dact_part; float dact_gpos, dact_gneg, dact_rail;
+    const float* post;      // forward tail only: the finished value is multiplied by post[n, c] (the style modulation of the layer that reads it next)
 };
 
 #define SBG_UPFIRDN_MAX_LDS_TAPS 1024
@@ -371,15 +372,17 @@ __global__ __launch_bounds__(256, RPW == 1 ? 3 : (RPW == 2 ? 2 : 1)) void upfird
     // channels -- block c + (fg & 1), offset 8 (fg >> 1) -- and stores 16 B instead of 2 x 8 B (the store path is issue-bound).
     T* yb = (T*)p.y + n * p.osn + cb0 * 64 + (fg & 1) * 16 + (fg >> 1) * 8;
     // fused tail, applied in fp32 before the exchange: this lane's channels are cb0*64 + 16 c + 4 fg + {0..3}
-    float4_t t_scale[4], t_bias[4];
+    float4_t t_scale[4], t_bias[4], t_post[4];
     const float t_alpha = p.tail ? p.alpha : 1.f, t_gain = p.tail ? p.act_gain : 1.f, t_cl = (p.tail && p.clamp >= 0.f) ? p.clamp : __builtin_inff();
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int ch = cb0 * 64 + c * 16 + 4 * fg;
         t_scale[c] = float4_t{p.gain, p.gain, p.gain, p.gain};
         t_bias[c] = float4_t{0.f, 0.f, 0.f, 0.f};
+        t_post[c] = float4_t{1.f, 1.f, 1.f, 1.f};
         if (p.tail && p.oscale) t_scale[c] *= *reinterpret_cast<const float4_t*>(p.oscale + (int64_t)n * p.C + ch);
         if (p.tail && p.bias)   t_bias[c] = *reinterpret_cast<const float4_t*>(p.bias + ch);
+        if (p.tail == 1 && p.post) t_post[c] = *reinterpret_cast<const float4_t*>(p.post + (int64_t)n * p.C + ch);
     }
 #pragma unroll
     for (int a = 0; a < RPW; a++) {
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(256, RPW == 1 ? 3 : (RPW == 2 ? 2 : 1)) void upfird
             for (int c = 0; c < 4; c++) {
                 float4_t v = acc[a][sg][c] * t_scale[c] + (t_bias[c] + nz);
 #pragma unroll
-                for (int e = 0; e < 4; e++) { float u = v[e]; u = (u > 0.f) ? u : u * t_alpha; v[e] = __builtin_amdgcn_fmed3f(u * t_gain, -t_cl, t_cl); }
+                for (int e = 0; e < 4; e++) { float u = v[e]; u = (u > 0.f) ? u : u * t_alpha; v[e] = __builtin_amdgcn_fmed3f(u * t_gain, -t_cl, t_cl) * t_post[c][e]; }
                 acc[a][sg][c] = v;
             }
 #pragma unroll
@@ -506,6 +509,13 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
 #pragma unroll
         for (int c = 0; c < 4; c++) t_bias[c] = *reinterpret_cast<const float4_t*>(p.bias + cb0 * 64 + c * 16 + 4 * fg);
     }
+    float4_t t_post[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) t_post[c] = float4_t{1.f, 1.f, 1.f, 1.f};
+    if (p.tail == 1 && p.post) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) t_post[c] = *reinterpret_cast<const float4_t*>(p.post + (int64_t)n * p.C + cb0 * 64 + c * 16 + 4 * fg);
+    }
     typedef __attribute__((ext_vector_type(4))) unsigned uint4_t;
     const T* ysv = BT ? (const T*)p.dact_y + n * p.osn + cb0 * 64 + (fg & 1) * 16 + (fg >> 1) * 8 : nullptr;      // the store layout of this lane (see below)
     const float d_gpos = p.dact_gpos, d_gneg = p.dact_gneg, d_rail = p.dact_rail;
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void upfirdn2d_fir_slide_kernel(UpfirdnArgs
             for (int c = 0; c < 4; c++) {
                 float4_t v = acc[sg][c] * t_scale[c] + (t_bias[c] + nz);
 #pragma unroll
-                for (int e = 0; e < 4; e++) { float u = v[e]; u = (u > 0.f) ? u : u * t_alpha; v[e] = __builtin_amdgcn_fmed3f(u * t_gain, -t_cl, t_cl); }
+                for (int e = 0; e < 4; e++) { float u = v[e]; u = (u > 0.f) ? u : u * t_alpha; v[e] = __builtin_amdgcn_fmed3f(u * t_gain, -t_cl, t_cl) * t_post[c][e]; }
                 pk[sg][c][0] = (unsigned)(unsigned short)FirMfma<T>::bits(v[0]) | ((unsigned)(unsigned short)FirMfma<T>::bits(v[1]) << 16);
                 pk[sg][c][1] = (unsigned)(unsigned short)FirMfma<T>::bits(v[2]) | ((unsigned)(unsigned short)FirMfma<T>::bits(v[3]) << 16);
             }
@@ -803,6 +813,8 @@ extern "C" int sbg_upfirdn2d(const sbg_upfirdn2d_params* q, sbg_stream_t stream)
     a.tail = (q->act != 0) ? 1 : 0;
     a.alpha = q->act == SBG_ACT_LRELU ? q->alpha : (q->act == SBG_ACT_RELU ? 0.f : 1.f); a.act_gain = q->act_gain; a.clamp = q->clamp;
     a.dact_y = nullptr; a.dact_part = nullptr; a.dact_gpos = a.dact_gneg = 1.f; a.dact_rail = __builtin_inff();
+    a.post = q->post_scale;
+    SBG_CHECK(!q->post_scale || (q->act != 0 && sbg_aligned16(q->post_scale)), "upfirdn2d: post_scale belongs to the forward tail (act != 0) and must be 16-byte aligned");
     if (q->dact_y) {        // backward tail: slope of clamp(act(.) * gain) at the saved output (same tests as sbg_modconv_bwd)
         SBG_CHECK(q->act == 0, "upfirdn2d: forward and backward tails exclude each other");
         SBG_CHECK(q->dact_partial != nullptr, "upfirdn2d: the backward tail needs dact_partial (sbg_upfirdn2d_dact_rows() x 64 floats)");

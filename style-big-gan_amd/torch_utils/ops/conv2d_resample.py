@@ -49,7 +49,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     `padding` is relative to the upsampled image.  Returns [N, Cout, H * up // down (+ padding), ...].
     `bias_act_tail` (extension): dict(b, act, alpha, gain, clamp) -- apply that bias_act to the result, fused into the
     convolution kernel when the convolution is the last stage.
-    `fir_tail` (extension, up-sampling branch): dict(dcoefs, noise, b, act, alpha, gain, clamp) -- the demodulation + noise + bias_act
+    `fir_tail` (extension, up-sampling branch): dict(dcoefs, noise, b, act, alpha, gain, clamp[, post]) -- the demodulation + noise + bias_act
     of a synthesis layer, fused into the low-pass kernel that ends the branch (first order only; the caller checks
     upfirdn2d.fir_tail_supported on the result of fir_tail_probe).
     `wgain` (extension): with 16-bit x, `w` may be the layer's fp32 parameter; the convolution operand is then cast(w * wgain), prepared
@@ -102,13 +102,15 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         fpad = [px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt]
         if fir_tail is not None and down == 1 and upfirdn2d.fir_tail_supported(x, f, fpad, flip_filter):
             return upfirdn2d.fir_bias_act(x, f, fpad, up ** 2, fir_tail["dcoefs"], fir_tail["noise"], fir_tail["b"], act=fir_tail["act"],
-                                          alpha=fir_tail["alpha"], act_gain=fir_tail["gain"], clamp=fir_tail["clamp"], flip_filter=flip_filter)
+                                          alpha=fir_tail["alpha"], act_gain=fir_tail["gain"], clamp=fir_tail["clamp"], flip_filter=flip_filter,
+                                          post_scale=fir_tail.get("post"))
         x = upfirdn2d.upfirdn2d(x, f, padding=fpad, gain=up ** 2, flip_filter=flip_filter)
         if fir_tail is not None:       # unfused composition of the same tail
             from . import modulate
             x = modulate.scale_nc(x, fir_tail["dcoefs"], fir_tail["noise"]) if fir_tail["dcoefs"] is not None else (x if fir_tail["noise"] is None else x + fir_tail["noise"].to(x.dtype))
-            return bias_act.bias_act(x, fir_tail["b"].to(x.dtype) if fir_tail["b"] is not None else None, act=fir_tail["act"], alpha=fir_tail["alpha"],
-                                     gain=fir_tail["gain"], clamp=(fir_tail["clamp"] if fir_tail["clamp"] >= 0 else None))
+            x = bias_act.bias_act(x, fir_tail["b"].to(x.dtype) if fir_tail["b"] is not None else None, act=fir_tail["act"], alpha=fir_tail["alpha"],
+                                  gain=fir_tail["gain"], clamp=(fir_tail["clamp"] if fir_tail["clamp"] >= 0 else None))
+            return x if fir_tail.get("post") is None else modulate.scale_nc(x, fir_tail["post"])
         if down > 1:
             x = upfirdn2d.upfirdn2d(x, f, down=down, flip_filter=flip_filter)
         return _tail(x, tail)

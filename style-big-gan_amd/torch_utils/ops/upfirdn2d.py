@@ -133,6 +133,8 @@ def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
             p.noise_stride_n = oh * ow if per_sample else 0
         p.act = {"linear": 1, "relu": 2, "lrelu": 3}[tail["act"]]
         p.alpha, p.act_gain, p.clamp = float(tail["alpha"]), float(tail["gain"]), float(tail["clamp"])
+        if tail.get("post") is not None:            # (inference) the next layer's style modulation applied on the way out
+            p.post_scale = f32(tail["post"], [n, c])
     _lib.check(lib.sbg_upfirdn2d(p, _lib.stream_ptr(x.device)), "sbg_upfirdn2d")
     return y
 
@@ -363,8 +365,13 @@ def fir_tail_supported(x, f, padding, flip_filter=False):
     return _launch(x, f, 1, 1, 1, 1, padx0, padx1, pady0, pady1, flip_filter, 1.0, probe=True)
 
 
-def fir_bias_act(x, f, padding, gain, dcoefs, noise, b, act="lrelu", alpha=0.2, act_gain=1.0, clamp=-1.0, flip_filter=False):
+def fir_bias_act(x, f, padding, gain, dcoefs, noise, b, act="lrelu", alpha=0.2, act_gain=1.0, clamp=-1.0, flip_filter=False, post_scale=None):
+    """`post_scale` [N, C] (inference only: no graph is recorded): the result times post_scale[n, c], i.e. already modulated for the layer that reads it"""
     padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    if post_scale is not None:
+        assert not (torch.is_grad_enabled() and (x.requires_grad or (dcoefs is not None and dcoefs.requires_grad))), "fir_bias_act: post_scale is an inference-only extension"
+        return _launch(x, f, 1, 1, 1, 1, padx0, padx1, pady0, pady1, bool(flip_filter), float(gain),
+                       tail=dict(oscale=dcoefs, noise=noise, bias=b, act=act, alpha=float(alpha), gain=float(act_gain), clamp=float(clamp), post=post_scale))
     cfg = (padx0, padx1, pady0, pady1, bool(flip_filter), float(gain), act, float(alpha), float(act_gain), float(clamp))
     handle = TailHandle(dcoefs, noise, b, act, float(alpha), float(act_gain), float(clamp))
     y = _FirBiasAct.apply(x, f, dcoefs, noise, b, cfg, handle)

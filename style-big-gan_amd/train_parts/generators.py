@@ -27,6 +27,8 @@ from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, conv_bi
 generators = utils.ClassRegistry()
 
 LOW_PRECISION = torch.bfloat16
+import os as _os
+premodulate = _os.environ.get('SBG_PREMODULATE', '1') != '0'     # inference passes: conv0's tail applies conv1's style modulation (SynthesisBlock.forward)
 
 
 def set_low_precision(dtype):
@@ -324,12 +326,17 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, x_sole_consumer=False):
-        """`x_sole_consumer` (extension): the caller guarantees that this layer is the only reader of x (a block's conv1 after its conv0), which lets
-        the fused training path chain the two layers' backward heads (ops/modconv.modconv_bias_act)"""
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, x_sole_consumer=False, post_scale=None, styles=None, x_premodulated=False):
+        """Extensions for the block that owns the layer:
+        `x_sole_consumer`: the caller guarantees that this layer is the only reader of x (a block's conv1 after its conv0), which lets the fused
+        training path chain the two layers' backward heads (ops/modconv.modconv_bias_act);
+        `post_scale` [N, Cout] (inference passes): return the output times post_scale[n, c] -- the NEXT layer's style modulation, applied in this layer's
+        last kernel when that is the fused low-pass tail -- to a reader that passes `x_premodulated=True` together with its `styles`."""
         assert noise_mode in ['random', 'const', 'none']
         misc.assert_shape(x, [None, self.weight.shape[1], self.resolution // self.up, self.resolution // self.up])
-        styles = self.affine(w)
+        assert not (post_scale is not None or x_premodulated) or not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or self.weight.requires_grad))
+        if styles is None:
+            styles = self.affine(w)
         noise = None
         if self.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
@@ -343,11 +350,13 @@ class SynthesisLayer(torch.nn.Module):
             # gain and clamp all ride in the convolution kernel's epilogue -- one read of x*s, one write of y
             with torch.no_grad():
                 dcoefs = demod_coefficients(self.weight, styles, x.dtype)
-                xs = modulate.scale_nc(x, styles)
+                xs = x if x_premodulated else modulate.scale_nc(x, styles)
                 spec = bias_act.activation_funcs[self.activation]
                 epi = conv2d_gradfix.Epilogue(oscale=dcoefs, noise=noise, bias=self.bias, act=self.activation, alpha=spec.def_alpha,
                                               gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1))
-                return conv2d_gradfix._conv_forward(xs, self.weight, (1, 1), (self.padding, self.padding), epi=epi)
+                y = conv2d_gradfix._conv_forward(xs, self.weight, (1, 1), (self.padding, self.padding), epi=epi)
+                return y if post_scale is None else modulate.scale_nc(y, post_scale)
+        assert not x_premodulated, 'x_premodulated: the caller checks premodulated_input_ok() first'
         if modconv.usable(x, self.weight, self.activation, self.up):
             # training pass, first order: same fused epilogue, plus a one-pass backward head (torch_utils/ops/modconv.py)
             return modconv.modconv_bias_act(x, self.weight, styles, demod_coefficients(self.weight, styles, x.dtype), noise, self.bias,
@@ -359,12 +368,19 @@ class SynthesisLayer(torch.nn.Module):
             # epilogue carries demodulation, noise, bias, activation, gain and clamp (falls back to the composition inside conv2d_resample)
             spec = bias_act.activation_funcs[self.activation]
             tail = dict(dcoefs=demod_coefficients(self.weight, styles, x.dtype), noise=noise, b=self.bias, act=self.activation, alpha=spec.def_alpha,
-                        gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1))
+                        gain=self.act_gain * gain, clamp=(clamp if clamp is not None else -1), post=post_scale)
             return conv2d_resample.conv2d_resample(x=modulate.scale_nc(x, styles), w=self.weight, f=self.resample_filter, up=2,
                                                    padding=self.padding, flip_weight=False, fir_tail=tail)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        x = bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        return x if post_scale is None else modulate.scale_nc(x, post_scale)
+
+    def premodulated_input_ok(self, dtype, device, records_graph):
+        """will forward(x_premodulated=True) take the inference branch that skips `x * styles`?  (what the caller checks before it asks the previous layer
+        for post_scale; `records_graph`: does anything that enters the pass require grad while grad mode is on)"""
+        return (not records_graph and not self.bias.requires_grad and self.up == 1 and self.activation in ('linear', 'relu', 'lrelu')
+                and dtype == torch.bfloat16 and device.type == 'cuda')
 
 
 class ToRGBLayer(torch.nn.Module):
@@ -468,10 +484,19 @@ class SynthesisBlock(torch.nn.Module):
         # main path: [conv0 (up-sampling)] -> conv1; 'resnet' adds a 1x1 up-sampling shortcut, both branches scaled by sqrt(1/2)
         residual = (not first) and self.architecture == 'resnet'
         shortcut = self.skip(x, gain=np.sqrt(0.5)) if residual else None
-        if not first:
-            x = self.conv0(x, next(w_iter), **lk)
         sole = not first        # conv0's output is read by conv1 and by nothing else
-        x = self.conv1(x, next(w_iter), gain=np.sqrt(0.5), x_sole_consumer=sole, **lk) if residual else self.conv1(x, next(w_iter), x_sole_consumer=sole, **lk)
+        g1 = np.sqrt(0.5) if residual else 1
+        records_graph = torch.is_grad_enabled() and (x.requires_grad or ws.requires_grad or self.conv1.weight.requires_grad or (sole and self.conv0.weight.requires_grad))
+        if sole and premodulate and self.conv1.premodulated_input_ok(dtype, x.device, records_graph):
+            # inference pass: conv0's last kernel hands conv1 its input already multiplied by conv1's styles (no `x * styles` pass in between)
+            w0, w1 = next(w_iter), next(w_iter)
+            styles1 = self.conv1.affine(w1)
+            x = self.conv0(x, w0, post_scale=styles1, **lk)
+            x = self.conv1(x, w1, gain=g1, styles=styles1, x_premodulated=True, **lk)
+        else:
+            if not first:
+                x = self.conv0(x, next(w_iter), **lk)
+            x = self.conv1(x, next(w_iter), gain=g1, x_sole_consumer=sole, **lk)
         if residual:
             x = shortcut + x     # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
         if self.attention is not None:

@@ -241,3 +241,35 @@ def test_synthesis_block_chained_backward_heads(dev):
                 continue
             ep, ec = l2(gp, gr), l2(gc, gr)
             assert ec <= 1.5 * ep + 5e-3, (arch, res, name, ep, ec)
+
+
+def test_synthesis_block_premodulated_inference(dev):
+    """inference passes of a synthesis block: conv0's last kernel (the fused low-pass tail) multiplies by conv1's styles, and conv1 skips its own
+    `x * styles` pass (SynthesisBlock.forward, `premodulate`).  Must give what the two-pass form gives -- up to the 16-bit rounding of the
+    intermediate that is no longer stored unscaled -- for a block whose conv0 takes the fused tail (64-channel blocks, >= 16 rows) and for small ones
+    that fall back to an explicit scale."""
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for arch, res, cin, cout in (("skip", 32, 128, 64), ("resnet", 64, 64, 128), ("skip", 16, 64, 64), ("skip", 32, 48, 40)):
+        torch.manual_seed(8)
+        B = PG.SynthesisBlock(in_channels=cin, out_channels=cout, w_dim=48, resolution=res, img_channels=3, is_last=False, architecture=arch, conv_clamp=256,
+                              use_fp16=True).to(dev)
+        with torch.no_grad():
+            for name, p in B.named_parameters():
+                if name.endswith("noise_strength"):
+                    p.fill_(0.3)
+        x = torch.randn(3, cin, res // 2, res // 2, device=dev)
+        img = torch.randn(3, 3, res // 2, res // 2, device=dev) if arch == "skip" else None
+        ws = torch.randn(3, B.num_conv + B.num_torgb, 48, device=dev)
+        outs = []
+        was = PG.premodulate
+        try:
+            for pre in (False, True):
+                PG.premodulate = pre
+                with torch.no_grad():
+                    y, im = B(x, None if img is None else img.clone(), ws, noise_mode="const")
+                outs.append((y.float(), None if im is None else im.float()))
+        finally:
+            PG.premodulate = was
+        assert l2(outs[1][0], outs[0][0]) < 1e-2, (arch, res, cin, l2(outs[1][0], outs[0][0]))
+        if outs[0][1] is not None:
+            assert l2(outs[1][1], outs[0][1]) < 1e-2
