@@ -32,6 +32,7 @@ from .. import utils
 from ..torch_utils import misc, training_stats
 from ..torch_utils.ops import conv_bias_act as _cba
 from ..torch_utils.ops import fromrgb as _fromrgb
+from ..torch_utils.ops import modconv as _modconv
 from ..utils import EasyDict
 from .losses import losses
 from .regularizations import R1reg, discriminator_regs, generator_regs
@@ -111,12 +112,16 @@ class LossBase:
         first_order_d = 'd_reg' not in passes
         fromrgb_was, _fromrgb.enabled = _fromrgb.enabled, first_order_d
         pairs_was, _cba.first_order = _cba.first_order, first_order_d and fuse_d_pairs
+        # generator regularisers (path length) differentiate G twice: their passes take the arbitrarily differentiable composition, every other pass the
+        # first-order fused synthesis layers (ops/modconv.py) -- a phase that holds both kinds ('Gboth') is conservative
+        modconv_was, _modconv.enabled = _modconv.enabled, _modconv.enabled and 'g_reg' not in passes
         try:
             for k, name in enumerate(passes):
                 getattr(self, '_pass_' + name)(rnd, closes_round=(k == len(passes) - 1), reg_follows=('d_reg' in passes[k + 1:]))
         finally:
             _fromrgb.enabled = fromrgb_was
             _cba.first_order = pairs_was
+            _modconv.enabled = modconv_was
 
     # -- the four passes ---------------------------------------------------------------------------------------------------
     def _pass_g_adv(self, rnd, closes_round, reg_follows):

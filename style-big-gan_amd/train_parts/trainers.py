@@ -106,9 +106,10 @@ class StepEngine:
                     self._ada_tap = training_stats.add_tap('Loss/signs/real', tap)
                     self._ada_adopt_at = None                   # iteration at whose start the pipe adopts the announced strength
             la['augment_pipe'] = self.augment_pipe
-        # the fused training-time synthesis layer is first order only: generator regularisers (path length) differentiate twice
+        # the fused training-time synthesis layers are first order only: the loss orchestration switches them off for the passes of a generator
+        # regulariser (path length differentiates G twice) and on for every other pass (losses_base.accumulate_gradients)
         from ..torch_utils.ops import modconv
-        modconv.enabled = len(list(gen_regs)) == 0
+        modconv.enabled = True
         self.loss = losses_arch[loss_arch](device=self.device, gen_regs=list(gen_regs), dis_regs=list(dis_regs),
                                            D=self.dp_modules['D'], loss=loss, **la)
 
