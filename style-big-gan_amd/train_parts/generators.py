@@ -558,9 +558,45 @@ class SynthesisNetwork(torch.nn.Module):
             per_block.append(ws.narrow(1, w_idx, block.num_conv + block.num_torgb))
             w_idx += block.num_conv
         x = img = None
-        for res, cur_ws in zip(self.block_resolutions, per_block):
+        plan = self.pass_plan(ws.shape[0]) if ws.shape[0] > 1 else None
+        tail, chunk = plan if plan is not None else (0, ws.shape[0])
+        head = len(self.block_resolutions) - tail
+        for res, cur_ws in zip(self.block_resolutions[:head], per_block[:head]):
             x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
+        if tail > 0:        # the highest-resolution blocks over slices of the batch (pass_plan), their images concatenated
+            imgs = []
+            for i in range(0, ws.shape[0], chunk):
+                xc, ic = x.narrow(0, i, chunk), (img.narrow(0, i, chunk) if img is not None else None)
+                for res, cur_ws in zip(self.block_resolutions[head:], per_block[head:]):
+                    xc, ic = getattr(self, f'b{res}')(xc, ic, cur_ws.narrow(0, i, chunk), **block_kwargs)
+                imgs.append(ic)
+            img = torch.cat(imgs)
         return img
+
+    pass_bytes_limit = 1 << 31      # the op layer addresses tensors below 2 GiB
+
+    def pass_plan(self, n):
+        """(k, chunk): the k highest-resolution blocks run over slices of `chunk` samples so that no tensor of a pass over n samples reaches
+        `pass_bytes_limit`; (0, n) = no slicing; None = not possible.  Blocks treat samples independently (no attention in the sliced blocks); the
+        counterpart of Discriminator.pass_plan for the generator's trailing blocks."""
+        cache = self.__dict__.setdefault('_pass_plans', {})
+        key = (n, self.pass_bytes_limit)
+        if key not in cache:
+            blocks = [getattr(self, f'b{res}') for res in self.block_resolutions]
+            peaks = [int(b.conv1.weight.shape[0]) * (b.resolution + 1) ** 2 * (2 if b.use_fp16 else 12) for b in blocks]
+            k = 0
+            while k < len(peaks) - 1 and n * peaks[-1 - k] >= self.pass_bytes_limit:
+                k += 1
+            plan = (0, n)
+            if k > 0:
+                plan = None
+                if not any(b.attention is not None for b in blocks[len(blocks) - k:]):
+                    for chunk in range(n // 2, 0, -1):
+                        if n % chunk == 0 and chunk * max(peaks[len(peaks) - k:]) < self.pass_bytes_limit:
+                            plan = (k, chunk)
+                            break
+            cache[key] = plan
+        return cache[key]
 
 
 Mappingkwargs = generators.make_dataclass_from_init(MappingNetwork.__init__, 'Mappingkwargs', None)

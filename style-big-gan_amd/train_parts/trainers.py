@@ -230,8 +230,9 @@ class StepEngine:
             return False
         hit = self._round_plan.get((phase_name, rounds))
         if hit is None:
-            peak = self.G.peak_activation_bytes() if hasattr(self.G, 'peak_activation_bytes') else 0
-            hit = rounds * self.batch_gpu * peak < (1 << 31) and self.loss.rounds_mergeable(phase_name, self.batch_gpu, rounds)
+            syn = getattr(self.G, 'synthesis', None)
+            fits = syn.pass_plan(rounds * self.batch_gpu) is not None if hasattr(syn, 'pass_plan') else True
+            hit = fits and self.loss.rounds_mergeable(phase_name, self.batch_gpu, rounds)
             self._round_plan[(phase_name, rounds)] = hit
         return hit
 

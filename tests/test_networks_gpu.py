@@ -273,3 +273,27 @@ def test_synthesis_block_premodulated_inference(dev):
         assert l2(outs[1][0], outs[0][0]) < 1e-2, (arch, res, cin, l2(outs[1][0], outs[0][0]))
         if outs[0][1] is not None:
             assert l2(outs[1][1], outs[0][1]) < 1e-2
+
+
+def test_synthesis_network_sliced_trailing_blocks(dev):
+    """a pass too large for the op layer's 2 GiB tensors runs the generator's highest-resolution blocks over slices of the batch
+    (SynthesisNetwork.pass_plan, the counterpart of Discriminator.pass_plan): same images, gradients reach the latents through the slices"""
+    torch.manual_seed(9)
+    G = PG.Generator(z_dim=32, c_dim=0, w_dim=32, img_resolution=64, img_channels=3, mapping_kwargs=dict(num_layers=2),
+                     synthesis_kwargs=dict(channel_base=2048, channel_max=64, num_fp16_res=8, block_kwargs=dict(conv_clamp=256))).to(dev)
+    syn = G.synthesis
+    ws = G.mapping(torch.randn(8, 32, device=dev), None).detach()
+    assert syn.pass_plan(8) == (0, 8)
+    with torch.no_grad():
+        whole = syn(ws, noise_mode="const")
+    syn.pass_bytes_limit = 4 * 32 * 65 * 65 * 2 + 1          # four samples of the 64x64 block (32 channels) fit, eight do not; nor do eight of the 32x32 block (64 channels)
+    try:
+        assert syn.pass_plan(8) == (2, 4)
+        with torch.no_grad():
+            sliced = syn(ws, noise_mode="const")
+        assert float((sliced - whole).abs().max()) <= 2e-3 * float(whole.abs().max())
+        wg = ws.clone().requires_grad_(True)
+        syn(wg, noise_mode="const").square().sum().backward()
+        assert bool(torch.isfinite(wg.grad).all()) and float(wg.grad.abs().sum()) > 0
+    finally:
+        del syn.pass_bytes_limit
