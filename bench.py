@@ -151,9 +151,32 @@ def pmc_traffic(kind):
     return (round(tot / n), os.path.relpath(files[-1], ROOT)) if n else (None, None)
 
 
-def cpu_baseline(sample_batch=2, res=RES):
-    """One Gmain + Dmain + Dreg pass of the CPU oracle on `sample_batch` images at the headline workload's shapes (fp32, all host
-    threads); returns img/s of a G+D step with Dreg amortised over 4 iterations, like the GPU figure."""
+def host_cores():
+    """CPU threads this process may really use: the scheduler affinity capped by the cgroup's cpu quota (a GPU box shows all of the
+    host's cores to os.cpu_count() while the job owns a share of them; timing the oracle on 128 threads over a 16-core share is what
+    made round 2's baseline slower than an 8-core container)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def cpu_worker(batch, threads, res=RES):
+    """One Gmain + Dmain + Dreg pass of the CPU oracle on `batch` images at the headline workload's shapes (fp32, `threads` host
+    threads); prints {'t_main', 't_reg'} in seconds.  Runs in a child process of the cpu_baseline leg; touches no GPU."""
+    torch.set_num_threads(threads)
     from oracle import networks as ON
     from style_big_gan_amd.train_parts import discriminators, generators
     torch.manual_seed(0)
@@ -164,7 +187,7 @@ def cpu_baseline(sample_batch=2, res=RES):
                          g_architecture='skip', d_architecture='orig', conv_clamp=None, mbstd_group_size=32)
     gsd = {k: v.detach().float() for k, v in G.state_dict().items()}
     dsd = {k: v.detach().float() for k, v in D.state_dict().items()}
-    n = sample_batch
+    n = batch
     z_g, z_d = torch.randn(n, Z_DIM), torch.randn(n, Z_DIM)
     real = torch.randint(0, 256, [n, 3, res, res]).float() / 127.5 - 1
     t0 = time.perf_counter()
@@ -178,67 +201,147 @@ def cpu_baseline(sample_batch=2, res=RES):
     pen = (r1.square().sum([1, 2, 3]) * 0.005).mean()
     torch.autograd.grad(pen, [v for v in d_leaf.values() if v.requires_grad], allow_unused=True)
     t_reg = time.perf_counter() - t0
-    sec_per_img = (t_main + t_reg / 4) / n
-    return dict(value=round(1.0 / sec_per_img, 4), unit='img/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'oracle/ (CPU restatement of the reference eager path, fp32), one Gmain+Dmain ({t_main:.1f}s) + one Dreg ({t_reg:.1f}s, /4) '
-                       f'on batch {n} at {res}x{res}, sg2ada shapes; at batch 2 the path does not scale with threads -- the reference proper, '
-                       'imported in the build container, ran the same passes at 0.18 img/s on 8 cores (BASELINE.md section 3)')
+    print(json.dumps(dict(t_main=t_main, t_reg=t_reg)))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None)
-    ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--workload', default='sg2ada', choices=['sg2ada', 'ffhq_sg2', 'sg2attent', 'big_gan'])
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--res', type=int, default=None, help='resolution override (sg2attent: 32 or 256; otherwise debug only)')
-    ap.add_argument('--batch', type=int, default=None, help='per-rank batch (weak) / global batch (strong); default: the config\'s')
-    ap.add_argument('--batch-gpu', type=int, default=None)
-    ap.add_argument('--ada', type=float, default=None, metavar='P', help="secondary measurement: 'bgc' ADA pipe on, starting strength P (headline = off)")
-    ap.add_argument('--num-fp16-res', type=int, default=None, metavar='K',
-                    help='secondary measurement: reduced precision in the K highest resolutions only (the reference recipe: 4; 0 = fp32 storage everywhere)')
-    ap.add_argument('--kernel-breakdown', action='store_true', help='print the per-kernel launch log summary to stderr')
-    ap.add_argument('--single-thread-autograd', action='store_true',
-                    help='run backward on the calling thread (profiling under rocprofv3 counter collection: see DESIGN.md, "queue interception")')
-    ap.add_argument('--launch-log', default=None, metavar='FILE', help='write the launch log of the timed region (one JSON record per launch, in launch order)')
-    args = ap.parse_args()
+def cpu_baseline(res=RES, budget_s=60.0):
+    """img/s of a G+D step (Dreg amortised over 4 iterations, like the GPU figure) of the CPU oracle on the host cores this job owns.
+    The split of those cores that maximises img/s is searched within `budget_s`: k concurrent processes x (cores / k) threads, each
+    running one Gmain + Dmain + Dreg on its own batch; a candidate is skipped when the budget left is less than the previous one took."""
+    import subprocess
+    cores = host_cores()
+    cands = [(1, cores, 2)]
+    k = 2
+    while cores // k >= 2 and k <= 8:
+        cands.append((k, cores // k, 2)); k *= 2
+    t_start, best, tried, last = time.perf_counter(), None, [], 0.0
+    for procs, threads, batch in cands:
+        if tried and budget_s - (time.perf_counter() - t_start) < 1.3 * last:
+            break
+        t0 = time.perf_counter()
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(batch), str(threads), '--res', str(res)],
+                               stdout=subprocess.PIPE, env=env, text=True) for _ in range(procs)]
+        outs = [q.communicate()[0] for q in ps]
+        last = time.perf_counter() - t0
+        if any(q.returncode != 0 for q in ps):
+            tried.append(dict(processes=procs, threads=threads, batch=batch, failed=True)); continue
+        rec = [json.loads(o.strip().splitlines()[-1]) for o in outs]
+        t_main, t_reg = max(r['t_main'] for r in rec), max(r['t_reg'] for r in rec)      # concurrent workers: the slowest one bounds the throughput
+        val = procs * batch / (t_main + t_reg / 4)
+        tried.append(dict(processes=procs, threads=threads, batch=batch, img_s=round(val, 4), t_main_s=round(t_main, 2), t_reg_s=round(t_reg, 2)))
+        if best is None or val > best[0]:
+            best = (val, procs, threads, batch, t_main, t_reg)
+    if best is None:
+        return None
+    val, procs, threads, batch, t_main, t_reg = best
+    return dict(value=round(val, 4), unit='img/s', cores=procs * threads, kind='port',
+                sample=f'oracle/ (CPU restatement of the reference eager path, fp32): {procs} process(es) x {threads} threads, each one Gmain+Dmain '
+                       f'({t_main:.1f}s) + one Dreg ({t_reg:.1f}s, /4) on batch {batch} at {res}x{res}, sg2ada shapes; best of the splits tried within '
+                       f'{budget_s:.0f}s on the {cores} host cores this job owns (os.cpu_count() = {os.cpu_count()}); the reference proper, imported in '
+                       'the build container, ran the same passes at 0.18 img/s on 8 cores (BASELINE.md section 3)',
+                splits_tried=tried)
 
+
+# ----------------------------------------------------------------------------------------------------------------------------------------
+# N ranks
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, the reference's starter.py:26-30) BEFORE
+    anything here has touched a GPU, give them the rendezvous through the environment, pass rank 0's JSON line through, and fail if any
+    rank fails.  -> exit code"""
+    import socket
+    import subprocess
+    backend = os.environ.get('SBG_DIST_BACKEND', 'nccl')
+    n_dev = torch.cuda.device_count()           # counting devices does not initialise the runtime
+    if backend == 'nccl' and n_dev < n:
+        print(f'bench.py --gpus {n}: {n} ranks need {n} devices, this machine has {n_dev} '
+              '(SBG_DIST_BACKEND=gloo rehearses the N-rank path with ranks sharing devices; it is not a measurement)', file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(n_dev, 1)), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    code = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 1
+                    print(f'bench.py: rank {r} exited with code {rc}; stopping the other ranks', file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return code
+
+
+def init_ranks(args):
+    """-> (world, rank, local_rank, backend, ranks_seen).  `ranks_seen` is an all-reduce of ones over the backend: the line proves how many
+    ranks took part."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a ROCm device (the hot path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}')
+    backend = None
+    seen = 1
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = os.environ.get('SBG_DIST_BACKEND', 'nccl')        # 'gloo' only to rehearse N > 1 on a one-GPU box
-        torch.distributed.init_process_group(backend, **(dict(device_id=device) if backend == 'nccl' else {}))
-    assert world == args.gpus or world == 1, f'launched with WORLD_SIZE={world} but --gpus {args.gpus}'
+        backend = os.environ.get('SBG_DIST_BACKEND', 'nccl')        # 'gloo' only to rehearse N > 1 on a one-GPU box / on the CPU
+        if backend == 'nccl':
+            if torch.cuda.device_count() <= local_rank:
+                raise SystemExit(f'bench.py: rank {rank} needs device {local_rank}, this machine has {torch.cuda.device_count()}')
+            torch.cuda.set_device(local_rank)
+            torch.distributed.init_process_group(backend, device_id=torch.device('cuda', local_rank))
+            ones = torch.ones([1], device=torch.device('cuda', local_rank))
+        else:
+            torch.distributed.init_process_group(backend)
+            ones = torch.ones([1])
+        torch.distributed.all_reduce(ones)
+        seen = int(ones.item())
+        if seen != world:
+            raise SystemExit(f'bench.py: {seen} ranks answered the all-reduce, {world} were launched')
+    return world, rank, local_rank, backend, seen
 
-    if args.single_thread_autograd:
-        torch.autograd.set_multithreading_enabled(False)
-    assert args.num_fp16_res is None or args.workload == 'sg2ada', '--num-fp16-res: headline workload only'
-    wl = workload(args.workload, args.res, args.num_fp16_res)
+
+# ----------------------------------------------------------------------------------------------------------------------------------------
+# one measurement
+
+def measure(args, device, world, rank, name, *, res=None, nfp=None, scaling='weak', steps=None, warmup=None, ada=None, batch_arg=None,
+            batch_gpu_arg=None, headline=True):
+    """Build the workload's engine, run `warmup` untimed and `steps` timed steps (barrier + synchronize on both sides, MAX over ranks) and
+    return the result record (rank 0: everything; other ranks: None)."""
+    from style_big_gan_amd import _lib
+    wl = workload(name, res, nfp)
     res = wl['res']
-    steps = args.steps if args.steps is not None else wl['steps']
-    cfg_batch = args.batch or wl['batch']
-    if args.scaling == 'strong':
-        assert cfg_batch % world == 0, f'strong scaling: global batch {cfg_batch} is not divisible by {world} ranks'
+    steps = steps if steps is not None else wl['steps']
+    warmup = args.warmup if warmup is None else warmup
+    cfg_batch = batch_arg or wl['batch']
+    if scaling == 'strong':
+        if cfg_batch % world:
+            raise SystemExit(f'strong scaling: global batch {cfg_batch} is not divisible by {world} ranks')
         batch = cfg_batch // world                                   # reference trainers.py:524
         global_batch = cfg_batch
     else:
         batch, global_batch = cfg_batch, cfg_batch * world
-    batch_gpu = min(args.batch_gpu or wl['batch_gpu'], batch)      # reference trainers.py:203-204
+    batch_gpu = min(batch_gpu_arg or wl['batch_gpu'], batch)      # reference trainers.py:203-204
     assert batch % batch_gpu == 0
 
-    import style_big_gan_amd  # noqa: F401
-    from style_big_gan_amd import _lib
-    _lib.load()
-    eng = build_engine(device, world, rank, wl, batch=batch, batch_gpu=batch_gpu, ada=args.ada)
+    eng = build_engine(device, world, rank, wl, batch=batch, batch_gpu=batch_gpu, ada=ada)
     gen = torch.Generator(device=device); gen.manual_seed(1234 + rank)
     real_u8 = torch.randint(0, 256, [batch, 3, res, res], device=device, dtype=torch.uint8, generator=gen)
     real_c = None
@@ -254,8 +357,20 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # warm-up, with the gradients of every phase checked BEFORE nan_to_num: a launch that produces NaN at these shapes would otherwise
+    # be zeroed by the sanitiser and the step would still post a throughput (parallel.GradReducer.finish)
+    eng.collect_comm_stats(True, nonfinite=True)
+    eng.batch_idx = 0
+    for _ in range(max(warmup, 1)):
         step()
+    barrier()
+    nonfinite = {ph: int(st['nonfinite'].item()) for ph, st in eng.comm_stats.items()}
+    bad = torch.tensor([sum(nonfinite.values())], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(bad)
+    if bad.item() > 0:
+        raise SystemExit(f'bench.py: {int(bad.item())} non-finite gradient elements during warm-up ({nonfinite} on rank {rank}): no value is reported')
+    eng.collect_comm_stats(True, nonfinite=False)
     eng.batch_idx = 0       # the timed region starts on an iteration on which every phase is due: K steps contain ceil(K / interval) of each
     barrier()
     _lib.prof_enable(True)
@@ -277,8 +392,35 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # gradient exchange: what the compute stream waited for (not hidden under backward) vs the same all-reduces alone on the wire
+    comm = None
+    if world > 1:
+        comm = {}
+        for ph in eng.phases:
+            st = eng.comm_stats.get(ph.name)
+            if ph.idle or st is None or not st['runs']:
+                continue
+            exposed = sum(a.elapsed_time(b) for a, b in st['pairs']) / st['runs']
+            flats = [b.flat for r in ph.reducers for b in r._buckets]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            barrier()
+            e0.record()
+            for _ in range(reps):
+                for f in flats:
+                    torch.distributed.all_reduce(f)
+            e1.record()
+            torch.cuda.synchronize()
+            alone = e0.elapsed_time(e1) / reps
+            nbytes = sum(f.numel() * f.element_size() for f in flats)
+            comm[ph.name] = dict(grad_mb=round(nbytes / 1e6, 1), buckets=len(flats), allreduce_ms_alone=round(alone, 3),
+                                 busbw_gbs=round(2 * (world - 1) / world * nbytes / (alone * 1e-3) / 1e9, 1),
+                                 exposed_ms_per_phase=round(exposed, 3), hidden_frac=round(min(max(1.0 - exposed / max(alone, 1e-9), 0.0), 1.0), 3))
+    eng.collect_comm_stats(False)
+
+    out = None
     if rank == 0:
-        if args.launch_log:
+        if args.launch_log and headline:
             with open(args.launch_log, 'w') as f:
                 for r in records:
                     f.write(json.dumps(dict(kind=r['kind'], dims=list(r['dims']), ms=round(r['ms'], 6), flops=r['flops'], bytes=r['bytes'])) + '\n')
@@ -297,7 +439,7 @@ def main():
                 roofline = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                                 frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                                 launches=k['launches'], avg_launch_ms=round(k['ms'] / k['launches'], 4))
-        if roofline is not None and args.workload == 'sg2ada':      # the committed PMC passes are of the headline workload
+        if roofline is not None and name == 'sg2ada' and nfp is None:      # the committed PMC passes are of the headline workload
             roofline['traffic'], src = pmc_traffic(dom)
             if src:
                 roofline['traffic_source'] = src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch averaged over the same launches)'
@@ -307,7 +449,7 @@ def main():
         one_pass = rounds > 1 and all(eng._rounds_in_one_pass(ph.name, rounds) for ph in eng.phases if not ph.idle)
         pass_batch = batch if one_pass else batch_gpu          # samples per network pass
         tgt = [r for r in records if r['kind'] == 'conv_igemm' and r['dims'][1] == 128 and r['dims'][2] == 128 and r['dims'][3] == 9
-               and r['dims'][0] == pass_batch * res * res] if args.workload == 'sg2ada' else []
+               and r['dims'][0] == pass_batch * res * res] if name == 'sg2ada' else []
         target = None
         if tgt:
             fl, ms = sum(r['flops'] for r in tgt), sum(r['ms'] for r in tgt)
@@ -318,7 +460,7 @@ def main():
         breakdown = {k: dict(launches=v['launches'], ms_per_step=round(v['ms'] / steps, 3),
                              tflops=round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 2), gbs=round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1))
                      for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['ms'])}
-        if args.kernel_breakdown:
+        if args.kernel_breakdown and headline:
             print(json.dumps(breakdown, indent=1), file=sys.stderr)
             shapes = {}
             for r in records:
@@ -327,33 +469,127 @@ def main():
             print('top launches by total time (kind, dims): launches, ms/step, avg us, TFLOP/s, GB/s', file=sys.stderr)
             for (kind, dims), (cnt, ms, fl, by) in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:90]:
                 print(f'  {kind:13s} {str(dims):52s} {cnt:5d} {ms / steps:8.3f} {ms / cnt * 1e3:9.1f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:8.1f}', file=sys.stderr)
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline and args.workload == 'sg2ada':
-            cpu = cpu_baseline(res=res)
         imgs = steps * global_batch
-        headline = args.workload == 'sg2ada'
-        if args.num_fp16_res == 0:
-            wl['dtype'] = 'f32'          # fp32 storage everywhere (convolutions as split-bf16 MFMA products, fp32 accumulate)
+        dtype = 'f32' if nfp == 0 else wl['dtype']          # num_fp16_res 0 = fp32 storage everywhere (convolutions as split-bf16 MFMA products, fp32 accumulate)
+        is_headline_metric = name == 'sg2ada' and res == 256 and dtype == 'bf16'
         out = {
-            'metric': 'images/sec (G+D step) StyleGAN2-ADA 256x256 bf16' if headline and res == 256 and wl['dtype'] == 'bf16' else f'images/sec (G+D step) {args.workload} {res}x{res} {wl["dtype"]}',
+            'metric': 'images/sec (G+D step) StyleGAN2-ADA 256x256 bf16' if is_headline_metric else f'images/sec (G+D step) {name} {res}x{res} {dtype}',
             'value': round(imgs / elapsed, 2), 'unit': 'img/s',
-            'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / steps * 1e3, 2),
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': wl['dtype'], 'data': 'synthetic',
+            'n_gpus': world, 'steps': steps, 'warmup': max(warmup, 1), 'ms_per_step': round(elapsed / steps * 1e3, 2),
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': f'{wl["label"]}, global batch {global_batch} = {world} rank(s) x {batch // batch_gpu} round(s) x batch_gpu {batch_gpu}'
                                    + (' (the rounds of a phase evaluated in one pass, minibatch-std groups and loss those of the separate rounds), ' if one_pass else ', ')
-                                   + ((f'bf16 from 8x8 up (num_fp16_res {_bf16_blocks(res)}; the reference recipe defaults to 4), conv_clamp 256, ' if args.num_fp16_res is None else
-                                       f'bf16 in the {args.num_fp16_res} highest resolutions (num_fp16_res {args.num_fp16_res}; secondary measurement), fp32 storage below, conv_clamp 256, ')
-                                      if wl['dtype'] == 'bf16' else 'fp32 storage, ')
-                                   + ('ADA off' if args.ada is None else f'ADA bgc on (p0 = {args.ada}, target 0.6; secondary measurement)'),
-                       'global_batch': global_batch, 'parallelism': f'dp{world}'},
-            'roofline': roofline, 'target_kernel': target, 'cpu_baseline': cpu,
+                                   + ((f'bf16 from 8x8 up (num_fp16_res {_bf16_blocks(res)}; the reference recipe defaults to 4), conv_clamp 256, ' if nfp is None else
+                                       f'bf16 in the {nfp} highest resolutions (num_fp16_res {nfp}; secondary measurement), fp32 storage below, conv_clamp 256, ')
+                                      if dtype == 'bf16' else 'fp32 storage, ')
+                                   + ('ADA off' if ada is None else f'ADA bgc on (p0 = {ada}, target 0.6; secondary measurement)'),
+                       'global_batch': global_batch, 'per_rank_batch': batch, 'parallelism': f'dp{world}'},
+            'roofline': roofline, 'target_kernel': target,
             'ms_per_step_median': round(step_ms[len(step_ms) // 2], 2),
             'step_tflops': round(total_flops / (elapsed * 1e3) / 1e9, 1),
             'kernel_ms_per_step': {k: v['ms_per_step'] for k, v in breakdown.items()},
             'sbg_kernel_time_frac_of_step': round(total_ms / (elapsed * 1e3), 3),
+            'nonfinite_grads': sum(nonfinite.values()),
         }
-        print(json.dumps(out))
+        if comm is not None:
+            out['comm'] = comm
     eng.close()
+    del eng, real_u8
+    torch.cuda.empty_cache()
+    return out
+
+
+def slim(rec):
+    """a secondary measurement inside the headline line: the numbers, not the per-kernel tables"""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'scaling', 'dtype', 'config', 'step_tflops',
+            'nonfinite_grads', 'comm')
+    out = {k: rec[k] for k in keep if k in rec}
+    if rec.get('roofline'):
+        out['roofline_frac'] = rec['roofline']['frac']
+    if rec.get('target_kernel'):
+        out['target_kernel_mfma_frac'] = rec['target_kernel']['mfma_frac']
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--workload', default='sg2ada', choices=['sg2ada', 'ffhq_sg2', 'sg2attent', 'big_gan'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong', 'both'],
+                    help="weak (default; the mode the >= 6x at 8 GPUs target is stated for): per-rank batch fixed; strong: global batch fixed; "
+                         "both: the weak line with the strong-scaling run in its `secondary` list")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='headline workload: skip the reference-recipe precision run (num_fp16_res 4) after the headline loop')
+    ap.add_argument('--res', type=int, default=None, help='resolution override (sg2attent: 32 or 256; otherwise debug only)')
+    ap.add_argument('--batch', type=int, default=None, help='per-rank batch (weak) / global batch (strong); default: the config\'s')
+    ap.add_argument('--batch-gpu', type=int, default=None)
+    ap.add_argument('--ada', type=float, default=None, metavar='P', help="secondary measurement: 'bgc' ADA pipe on, starting strength P (headline = off)")
+    ap.add_argument('--num-fp16-res', type=int, default=None, metavar='K',
+                    help='secondary measurement: reduced precision in the K highest resolutions only (the reference recipe: 4; 0 = fp32 storage everywhere)')
+    ap.add_argument('--kernel-breakdown', action='store_true', help='print the per-kernel launch log summary to stderr')
+    ap.add_argument('--single-thread-autograd', action='store_true',
+                    help='run backward on the calling thread (profiling under rocprofv3 counter collection: see DESIGN.md, "queue interception")')
+    ap.add_argument('--launch-log', default=None, metavar='FILE', help='write the launch log of the timed region (one JSON record per launch, in launch order)')
+    ap.add_argument('--rendezvous-only', action='store_true', help='start the ranks, count them with an all-reduce, print that and stop (launcher test; no GPU work)')
+    ap.add_argument('--cpu-worker', nargs=2, type=int, default=None, metavar=('BATCH', 'THREADS'), help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.cpu_worker is not None:
+        cpu_worker(args.cpu_worker[0], args.cpu_worker[1], res=args.res or RES)
+        return
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    world, rank, local_rank, backend, ranks_seen = init_ranks(args)
+    if args.rendezvous_only:
+        if rank == 0:
+            print(json.dumps(dict(ranks_seen=ranks_seen, n_gpus=world, backend=backend)))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (the hot path has no CPU fallback)')
+    n_dev = torch.cuda.device_count()
+    local = local_rank % n_dev
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    if args.single_thread_autograd:
+        torch.autograd.set_multithreading_enabled(False)
+    assert args.num_fp16_res is None or args.workload == 'sg2ada', '--num-fp16-res: headline workload only'
+
+    import style_big_gan_amd  # noqa: F401
+    from style_big_gan_amd import _lib
+    _lib.load()
+    first_scaling = 'weak' if args.scaling == 'both' else args.scaling
+    common = dict(res=args.res, ada=args.ada, batch_arg=args.batch, batch_gpu_arg=args.batch_gpu)
+    out = measure(args, device, world, rank, args.workload, nfp=args.num_fp16_res, scaling=first_scaling, steps=args.steps, **common)
+
+    secondary = []
+    plain_headline = args.workload == 'sg2ada' and args.num_fp16_res is None and args.ada is None and args.res is None
+    if args.scaling == 'both' and world > 1:
+        rec = measure(args, device, world, rank, args.workload, nfp=args.num_fp16_res, scaling='strong', steps=args.steps, headline=False, **common)
+        if rank == 0:
+            secondary.append(slim(rec))
+    if plain_headline and not args.no_secondary and world == 1:
+        # the reference recipe's precision split (bf16 in the 4 highest resolutions, fp32 storage below) on the same clock, same process
+        rec = measure(args, device, world, rank, 'sg2ada', nfp=4, scaling=first_scaling, steps=args.steps, headline=False, **common)
+        if rank == 0:
+            secondary.append(slim(rec))
+
+    if rank == 0:
+        out['ranks_seen'] = ranks_seen
+        out['scaling_note'] = ('weak: every rank runs the config\'s batch (global batch x N); strong: the config\'s global batch split over the ranks '
+                               '(reference trainers.py:524).  The >= 6x at 8 GPUs target of BASELINE.json is stated for the WEAK line.')
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'sg2ada':
+            cpu = cpu_baseline(res=args.res or RES)
+        out['cpu_baseline'] = cpu
+        if secondary:
+            out['secondary'] = secondary
+        print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -21,12 +21,21 @@ per accumulation round; a phase with two regularisers runs two per round) are le
 the invariant ``flat = mean over ranks of what was exchanged so far + this rank's gradients since``.  A forward through the
 wrapper first *settles* whatever an earlier backward left in flight (wait, scale by 1/world) so that the next backward never
 accumulates into a buffer RCCL is still reducing; the next exchange then sums ``mean_so_far + local_new`` over the ranks and
-the 1/world scaling gives ``mean_so_far + mean_new``.
+the 1/world scaling gives ``mean_so_far + mean_new``.  A backward that arrives WITHOUT a forward in between (two regularisers
+of one round differentiating the same logits) is covered by a tensor hook on every parameter, which autograd runs BEFORE it
+accumulates the gradient: it settles that parameter's bucket if an exchange is in flight.  Readiness is per backward: arming a
+forward clears what an earlier backward left half-marked (parameters it did not reach).
+
+Instrumentation for ``bench.py`` (off by default, no host synchronisation when on): ``timing`` collects a device-event pair
+around every wait for an exchange -- the time the compute stream is actually stalled by the collective, i.e. what backward did
+NOT hide --, ``nonfinite`` accumulates the count of non-finite gradient elements per ``finish()`` BEFORE ``nan_to_num`` erases
+them.
 
 With ``world_size == 1`` nothing is communicated and the class is just the flat-gradient container.  The collective backend
 is whatever ``torch.distributed`` was initialised with: ``nccl`` (= RCCL) on GPUs, ``gloo`` in the CPU tests.
 """
 import contextlib
+import time
 
 import torch
 import torch.distributed as dist
@@ -60,6 +69,8 @@ class GradReducer(torch.nn.Module):
         self._armed = True              # latched at forward(): does the next backward all-reduce?
         self._buckets = []
         self._bucket_of = dict()
+        self.timing = None              # list of (event, event) / (t0, t1) pairs around waits when bench.py switches it on
+        self.nonfinite = None           # device scalar: non-finite gradient elements seen by finish() before nan_to_num
 
         params = [p for p in module.parameters()]
         if self.world_size > 1 and broadcast:
@@ -86,16 +97,21 @@ class GradReducer(torch.nn.Module):
                 p.grad = _grad_view(flat, off, p)
                 off += p.numel()
                 self._bucket_of[id(p)] = b
-                was = p.requires_grad       # hooks can only be registered while the tensor requires grad
-                p.requires_grad_(True)
-                p.register_post_accumulate_grad_hook(self._on_grad)
-                p.requires_grad_(was)
+                if self.world_size > 1:     # a single rank exchanges nothing: no per-parameter callbacks in its backward
+                    was = p.requires_grad   # hooks can only be registered while the tensor requires grad
+                    p.requires_grad_(True)
+                    p.register_hook(lambda g, b=b: self._before_grad(b))         # runs before the gradient is accumulated
+                    p.register_post_accumulate_grad_hook(self._on_grad)
+                    p.requires_grad_(was)
             self._buckets.append(b)
 
     # -- module passthrough -----------------------------------------------------------------------------------------
     def forward(self, *args, **kwargs):
         self._armed = self._sync_enabled
         self._settle()              # an earlier backward of this phase may still be on the wire: complete it before the next one accumulates
+        if self._armed:
+            for b in self._buckets:     # readiness is per backward: forget parameters an earlier backward marked and this one may not reach
+                b.ready.clear()
         return self.module(*args, **kwargs)
 
     def __getattr__(self, name):
@@ -132,21 +148,37 @@ class GradReducer(torch.nn.Module):
             b.dirty = False
             b.ready.clear()
 
+    def _wait(self, b):
+        """complete bucket b's exchange and turn its sum into a mean"""
+        if self.timing is None:
+            b.work.wait()
+        elif b.flat.is_cuda:        # work.wait() makes the compute stream wait for RCCL's: the event pair brackets exactly that stall
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); b.work.wait(); e1.record()
+            self.timing.append((e0, e1))
+        else:
+            t0 = time.perf_counter(); b.work.wait()
+            self.timing.append((t0, time.perf_counter()))
+        b.work = None
+        b.flat.mul_(1.0 / self.world_size)
+
     def _settle(self):
         """wait for the exchanges in flight and turn their sums into means"""
         for b in self._buckets:
             if b.work is not None:
-                b.work.wait()
-                b.work = None
-                b.flat.mul_(1.0 / self.world_size)
+                self._wait(b)
+
+    def _before_grad(self, b):
+        """tensor hook of every parameter: autograd calls it before it accumulates into the bucket's view.  A backward that runs without
+        a forward through the wrapper since the last synchronising backward finds the bucket on the wire: finish that exchange first."""
+        if b.work is not None:
+            self._wait(b)
 
     def _on_grad(self, p):
         if self.world_size <= 1:
             return
         b = self._bucket_of[id(p)]
-        if b.work is not None:      # forward() settles in-flight exchanges; a gradient arriving now would race with RCCL's reduction
-            raise RuntimeError("GradReducer: gradient accumulated into a bucket whose all-reduce is in flight "
-                               "(a backward ran without a forward through the wrapper since the last synchronising backward)")
+        assert b.work is None, "GradReducer: gradient accumulated into a bucket whose all-reduce is in flight"
         b.dirty = True
         if not self._armed:
             return
@@ -166,8 +198,19 @@ class GradReducer(torch.nn.Module):
             self._settle()
         for b in self._buckets:
             b.ready.clear()
+            if self.nonfinite is not None:
+                self.nonfinite += (~torch.isfinite(b.flat)).sum()
             if nan_to_num:
                 torch.nan_to_num(b.flat, nan=0, posinf=1e5, neginf=-1e5, out=b.flat)
+
+    def exposed_wait_ms(self, reset=True):
+        """sum of the stalls recorded in `timing` (ms); the caller synchronises the device first"""
+        pairs, total = self.timing or [], 0.0
+        for a, b in pairs:
+            total += a.elapsed_time(b) if isinstance(a, torch.cuda.Event) else (b - a) * 1e3
+        if reset and self.timing is not None:
+            self.timing = []
+        return total
 
     def grad_bytes(self):
         return sum(b.flat.numel() * b.flat.element_size() for b in self._buckets)

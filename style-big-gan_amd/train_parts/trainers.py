@@ -63,6 +63,8 @@ class StepEngine:
         self.cur_nimg = 0
         self.batch_idx = 0
         self._round_plan = {}
+        self._count_nonfinite = False
+        self.comm_stats = None      # bench.py: {phase: dict(pairs=[event pairs around waits for exchanges], nonfinite=device counter)}
 
         torch.manual_seed(seed * max(world_size, 1) + rank)     # reference :507-508
         self.G = generators[generator](**(gen_kwargs or {})).train().requires_grad_(False).to(self.device)
@@ -188,8 +190,17 @@ class StepEngine:
                         self.loss.accumulate_gradients(phase=phase.name, real_img=img, real_c=c, gen_z=z, gen_c=gc, sync=sync, gain=phase.interval)
                 phase.module.requires_grad_(False)
             with torch.autograd.profiler.record_function(phase.name + '_opt'):
+                st = self.comm_stats.setdefault(phase.name, dict(pairs=[], nonfinite=torch.zeros([], dtype=torch.int64, device=self.device), runs=0)) \
+                    if self.comm_stats is not None else None
                 for r in phase.reducers:
+                    if st is not None and self._count_nonfinite:
+                        r.nonfinite = st['nonfinite']
                     r.finish()              # wait for the all-reduce, average, nan_to_num (reference :745-747)
+                    if st is not None:
+                        st['pairs'].extend(r.timing or []); r.timing = []
+                        r.nonfinite = None
+                if st is not None:
+                    st['runs'] += 1
                 phase.opt.step()
 
         if self.G_ema is not None:
@@ -216,6 +227,16 @@ class StepEngine:
                 # the sampler keeps the old strength for exactly one more iteration, then switches (deterministic, identical on all ranks)
                 self.augment_pipe.announce_strength_update()
                 self._ada_adopt_at = self.batch_idx + 1
+
+    def collect_comm_stats(self, on=True, nonfinite=True):
+        """bench.py: per phase, the device-event pairs around every wait for a gradient exchange (what backward did not hide) and, with
+        `nonfinite`, the number of non-finite gradient elements BEFORE nan_to_num (one more pass over the flat buckets per phase: warm-up
+        only).  No host synchronisation; read after torch.cuda.synchronize()."""
+        self.comm_stats = {} if on else None
+        self._count_nonfinite = bool(nonfinite)
+        for r in self.dp_modules.values():
+            r.timing = [] if on else None
+            r.nonfinite = None
 
     def _rounds_in_one_pass(self, phase_name, rounds):
         """The accumulation rounds of a phase exist in the reference because a round is what fits its device (`batch_gpu`); here 288 GB hold

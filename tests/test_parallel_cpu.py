@@ -97,6 +97,42 @@ def _worker(rank, world, init_file, results):
             dist.all_gather(both, red._buckets[0].flat)
             assert torch.equal(both[0], both[1]), "ranks hold different gradients after finish()"
 
+        # TWO synchronising backwards behind ONE forward (two regularisers of a round differentiating the same logits), the first of
+        # which reaches only part of the parameters: its half-marked buckets must not launch early in the next armed backward, and the
+        # second backward must not accumulate into a bucket that the first one put on the wire (pre-accumulation hook settles it)
+        red.zero_grad()
+        with misc.ddp_sync(red, sync=True):
+            h = red.module[1](red.module[0](xs[0]))         # the wrapper's forward arms; run the layers by hand to get at the middle
+            y = red(xs[0])
+        tail_only = red.module[3](red.module[2](h.detach())).square().mean()       # gradients for layers 2, 3 only
+        tail_only.backward()
+        y.square().mean().backward(retain_graph=True)       # all parameters; buckets of layers 2, 3 may be in flight from `tail_only`
+        y.abs().mean().backward()                            # and again, no forward in between
+        red.finish()
+        for q in ref.parameters():
+            q.grad = None
+        hr = ref[1](ref[0](xs[0]))
+        ref[3](ref[2](hr.detach())).square().mean().backward()
+        yr = ref(xs[0])
+        yr.square().mean().backward(retain_graph=True); yr.abs().mean().backward()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            g = q.grad.clone()
+            dist.all_reduce(g)
+            assert torch.allclose(p.grad, g / world, atol=1e-6), "backwards sharing one forward: wrong gradient"
+
+        # instrumentation bench.py switches on: stalls behind exchanges, non-finite gradient elements before nan_to_num
+        red.timing, red.nonfinite = [], torch.zeros([], dtype=torch.int64)
+        red.zero_grad()
+        with misc.ddp_sync(red, sync=False):                # nothing on the wire until finish(): the buckets can be written by hand
+            y = red(xs[1])
+        y.square().mean().backward()
+        if rank == 0:
+            red._buckets[-1].flat[0] = float("nan")         # after the exchange every rank sees it
+        red.finish()
+        assert len(red.timing) >= 1 and red.exposed_wait_ms() >= 0.0 and red.timing == []
+        assert int(red.nonfinite) >= 1
+        red.timing, red.nonfinite = None, None
+
         # nan_to_num on the flat buckets
         red.zero_grad()
         red._buckets[0].flat[0] = float("nan"); red._buckets[0].flat[1] = float("inf")
