@@ -14,6 +14,7 @@ _MAP = {
     "train_parts.augmentations": "train_parts.augmentations",
     "train_parts.datasets": "train_parts.datasets",
     "train_parts.dataloaders": "train_parts.dataloaders",
+    "stylegan2ada.torch_utils.custom_ops": "torch_utils.custom_ops",
     "stylegan2ada.torch_utils.misc": "torch_utils.misc",
     "stylegan2ada.torch_utils.training_stats": "torch_utils.training_stats",
     "train_parts.generators": "train_parts.generators",

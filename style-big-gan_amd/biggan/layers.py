@@ -270,8 +270,114 @@ def normalize(x, mean, var, gain, bias, eps):
     return x * scale.reshape(n, c, 1, 1).to(x.dtype) + shift.reshape(n, c, 1, 1).to(x.dtype)
 
 
+def _moments_nc(x):
+    """per-sample, per-channel (sum x, sum x^2) over (H, W) in fp32: [N, C] each, differentiable"""
+    if x.device.type == "cuda":
+        return modulate.dot_hw(x), modulate.dot_hw(x, x)
+    xf = x.float()
+    return xf.sum([2, 3]), xf.square().sum([2, 3])
+
+
+def _scale_shift(x, scale, shift):
+    """x * scale[n, c] + shift[n, c] in one streaming pass"""
+    n, c = x.shape[0], x.shape[1]
+    scale, shift = scale.expand(n, c), shift.expand(n, c)
+    if x.device.type == "cuda":
+        return modulate.scale_shift_nc(x, scale, shift)
+    return x * scale.reshape(n, c, 1, 1).to(x.dtype) + shift.reshape(n, c, 1, 1).to(x.dtype)
+
+
+def instance_norm(mod, x, gain, bias):
+    """F.instance_norm(x, stored_mean, stored_var, None, None, training, 0.1, eps) * gain + bias (reference :317-319): statistics per sample
+    and channel over (H, W) while training -- the running buffers receive the batch mean of the per-instance mean and UNBIASED variance, which
+    is what torch's instance_norm does through its [1, N*C, H, W] batch-norm view --, the stored statistics otherwise."""
+    n, c, h, w = x.shape
+    if mod.training:
+        s1, s2 = _moments_nc(x)
+        hw = float(h * w)
+        mean = s1 / hw
+        var = (s2 / hw - mean.square()).clamp(min=0)
+        with torch.no_grad():
+            mod.stored_mean.mul_(0.9).add_(mean.detach().mean(0) * 0.1)
+            mod.stored_var.mul_(0.9).add_((var.detach() * (hw / max(hw - 1, 1))).mean(0) * 0.1)
+    else:
+        mean, var = mod.stored_mean.reshape(1, c), mod.stored_var.reshape(1, c)
+    scale = torch.rsqrt(var + mod.eps) * gain.reshape(-1, c)
+    return _scale_shift(x, scale, bias.reshape(-1, c) - mean * scale)
+
+
+def group_norm_groups(norm_style, channels):
+    """number of groups a norm_style string asks for (reference `groupnorm`, :257-268): 'gn_ch_<k>' = k channels per group, 'gn_grp_<g>' = g
+    groups, plain 'gn' = 16 groups"""
+    if 'ch' in norm_style:
+        return max(int(channels) // int(norm_style.split('_')[-1]), 1)
+    if 'grp' in norm_style:
+        return int(norm_style.split('_')[-1])
+    return 16
+
+
+def group_norm(x, groups, gain, bias, eps=1e-5):
+    """F.group_norm(x, groups) * gain + bias: statistics per sample over (C / groups, H, W), biased variance, eps = F.group_norm's default
+    (the reference does not pass its own, :268).  The reference's 'gn' branch reads a mistyped attribute (`self.normstyle`, :321) and cannot
+    run; this is the behaviour it spells out."""
+    n, c, h, w = x.shape
+    if c % groups:
+        raise ValueError(f"group norm: {c} channels are not divisible into {groups} groups")
+    s1, s2 = _moments_nc(x)
+    cnt = float((c // groups) * h * w)
+    g1 = s1.reshape(n, groups, -1).sum(-1, keepdim=True) / cnt
+    g2 = s2.reshape(n, groups, -1).sum(-1, keepdim=True) / cnt
+    mean = g1.expand(n, groups, c // groups).reshape(n, c)
+    var = (g2 - g1.square()).clamp(min=0).expand(n, groups, c // groups).reshape(n, c)
+    scale = torch.rsqrt(var + eps) * gain.reshape(-1, c)
+    return _scale_shift(x, scale, bias.reshape(-1, c) - mean * scale)
+
+
+class myBN(nn.Module):
+    """the reference's hand-written batch norm with standing statistics (:212-253): normalises with mean-of-squares minus squared-mean (BIASED
+    variance), keeps running averages of the SAME biased variance -- unlike F.batch_norm, which stores the unbiased one -- or, with
+    `accumulate_standing`, plain sums + a counter that evaluation divides by."""
+
+    def __init__(self, num_channels, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.momentum, self.eps = momentum, eps
+        self.register_buffer('stored_mean', torch.zeros(num_channels))
+        self.register_buffer('stored_var', torch.ones(num_channels))
+        self.register_buffer('accumulation_counter', torch.zeros(1))
+        self.accumulate_standing = False
+        self.cross_replica = False
+
+    def reset_stats(self):
+        self.stored_mean.zero_(); self.stored_var.zero_(); self.accumulation_counter.zero_()
+
+    def forward(self, x, gain, bias):
+        c = x.shape[1]
+        if self.training:
+            mean, var, _, _ = batch_stats(x, False)
+            with torch.no_grad():
+                if self.accumulate_standing:
+                    self.stored_mean.add_(mean.detach()); self.stored_var.add_(var.detach()); self.accumulation_counter.add_(1.0)
+                else:
+                    self.stored_mean.mul_(1 - self.momentum).add_(mean.detach() * self.momentum)
+                    self.stored_var.mul_(1 - self.momentum).add_(var.detach() * self.momentum)
+        else:
+            mean, var = self.stored_mean, self.stored_var
+            if self.accumulate_standing:
+                mean, var = mean / self.accumulation_counter, var / self.accumulation_counter
+        return normalize(x, mean, var, gain.reshape(-1, c), bias.reshape(-1, c), self.eps)
+
+
+NORM_STYLES = ('bn', 'in', 'gn', 'nonorm')
+
+
+def _check_norm_style(norm_style):
+    if norm_style not in NORM_STYLES and not norm_style.startswith('gn_'):
+        raise NotImplementedError(f"norm_style={norm_style!r}: one of {NORM_STYLES} (or 'gn_ch_<k>' / 'gn_grp_<g>')")
+
+
 class ccbn(nn.Module):
-    """class-conditional batch norm: gain = 1 + Emb/Linear(y), bias = Emb/Linear(y)"""
+    """class-conditional batch norm: gain = 1 + Emb/Linear(y), bias = Emb/Linear(y) (reference :275-327).  `mybn` = the hand-written batch norm
+    with standing statistics (buffers under `bn.`, as in the reference); norm_style 'bn' | 'in' | 'gn' | 'nonorm'."""
 
     def __init__(self, output_size, input_size, which_linear, eps=1e-5, momentum=0.1, cross_replica=False, mybn=False, norm_style='bn'):
         super().__init__()
@@ -280,25 +386,36 @@ class ccbn(nn.Module):
         self.bias = which_linear(input_size, output_size)
         self.eps, self.momentum = eps, momentum
         self.cross_replica, self.mybn, self.norm_style = cross_replica, mybn, norm_style
-        assert norm_style in ['bn', 'nonorm'], "norm_style 'bn' (and 'nonorm') are implemented"
-        # statistics live on this module ('stored_mean' / 'stored_var', the reference's buffer names for the default path)
-        self.register_buffer('stored_mean', torch.zeros(output_size))
-        self.register_buffer('stored_var', torch.ones(output_size))
+        _check_norm_style(norm_style)
+        if self.mybn and not self.cross_replica:
+            self.bn = myBN(output_size, self.eps, self.momentum)
+        elif self.cross_replica or norm_style in ('bn', 'in'):
+            # statistics live on this module ('stored_mean' / 'stored_var', the reference's buffer names for the default path)
+            self.register_buffer('stored_mean', torch.zeros(output_size))
+            self.register_buffer('stored_var', torch.ones(output_size))
 
     def forward(self, x, y):
         n = y.size(0)
         gain = (1 + self.gain(y)).view(n, -1)
         bias = self.bias(y).view(n, -1)
-        if self.norm_style == 'nonorm':
-            return normalize(x, torch.zeros_like(self.stored_mean), torch.ones_like(self.stored_var) - self.eps, gain, bias, self.eps)
-        return _bn_forward(self, x, gain, bias, momentum=0.1)     # F.batch_norm(..., 0.1, eps) in the reference (:315-316)
+        if self.cross_replica:
+            return _bn_forward(self, x, gain, bias, momentum=self.momentum)
+        if self.mybn:
+            return self.bn(x, gain, bias)
+        if self.norm_style == 'bn':
+            return _bn_forward(self, x, gain, bias, momentum=0.1)     # F.batch_norm(..., 0.1, eps) in the reference (:315-316)
+        if self.norm_style == 'in':
+            return instance_norm(self, x, gain, bias)
+        if self.norm_style.startswith('gn'):
+            return group_norm(x, group_norm_groups(self.norm_style, x.shape[1]), gain, bias)
+        return _scale_shift(x, gain, bias)                            # 'nonorm'
 
     def extra_repr(self):
         return f'out: {self.output_size}, in: {self.input_size}, cross_replica={self.cross_replica}'
 
 
 class bn(nn.Module):
-    """plain batch norm with learned per-channel gain / bias"""
+    """plain batch norm with learned per-channel gain / bias (reference :331-364)"""
 
     def __init__(self, output_size, eps=1e-5, momentum=0.1, cross_replica=False, mybn=False):
         super().__init__()
@@ -307,10 +424,15 @@ class bn(nn.Module):
         self.bias = P(torch.zeros(output_size), requires_grad=True)
         self.eps, self.momentum = eps, momentum
         self.cross_replica, self.mybn = cross_replica, mybn
-        self.register_buffer('stored_mean', torch.zeros(output_size))
-        self.register_buffer('stored_var', torch.ones(output_size))
+        if self.mybn and not self.cross_replica:
+            self.bn = myBN(output_size, self.eps, self.momentum)
+        else:
+            self.register_buffer('stored_mean', torch.zeros(output_size))
+            self.register_buffer('stored_var', torch.ones(output_size))
 
     def forward(self, x, y=None):
+        if self.mybn and not self.cross_replica:
+            return self.bn(x, self.gain.view(1, -1), self.bias.view(1, -1))
         return _bn_forward(self, x, self.gain.view(1, -1), self.bias.view(1, -1), momentum=self.momentum)
 
 

@@ -23,8 +23,12 @@ from ..utils import EasyDict
 
 
 class MetricOptions:
-    """G + how to call it, the data set, the process layout, and where the feature detector comes from.  ``detector``: a callable or the
-    path of a local TorchScript file; it overrides the detector name a metric asks for (there is no URL fetch in this build)."""
+    """G + how to call it, the data set, the process layout, and where the feature detector comes from (there is no URL fetch in this build).
+    ``detector`` overrides the detector a metric asks for: a callable (called as ``detector(images)``: it decides by itself what it returns, so
+    the metric's ``detector_kwargs`` are NOT passed), the path of a local TorchScript file (called with the metric's ``detector_kwargs`` --
+    ``return_features`` / ``no_output_bias`` -- like the reference's own files; accepted only for metrics whose expected detector has that
+    file name, so that an Inception file is never used where VGG16 features are asked for), or a dict ``{detector file name or stem: path |
+    callable}`` covering several metrics.  ``detector_dir``: a directory holding files under the reference's names."""
 
     def __init__(self, G=None, G_kwargs={}, dataset_kwargs={}, num_gpus=1, rank=0, device=None, progress=None, cache=True, detector=None,
                  detector_dir=None, cache_dir=None):
@@ -230,9 +234,35 @@ class ProgressMonitor:
 
 # ------------------------------------------------------------------------------------------------------------------------------
 
+def detector_source(opts, detector_url):
+    """what stands in for the detector `detector_url` (a reference file name) under `opts`: a callable or a path"""
+    src = opts.detector
+    if src is None:
+        return detector_url
+    if isinstance(src, dict):
+        name = str(detector_url).split('/')[-1]
+        for key in (name, get_feature_detector_name(name)):
+            if key in src:
+                return src[key]
+        raise RuntimeError(f'no local detector for {name}: MetricOptions(detector=...) maps {sorted(src)}')
+    if callable(src):
+        return src
+    want, have = get_feature_detector_name(detector_url), get_feature_detector_name(src)
+    if want != have:
+        raise RuntimeError(f'this metric computes on {want} features; the single detector file given is {os.path.basename(str(src))}. Pass a '
+                           'directory (detector_dir) holding the reference file names, or a dict {name: path} (MetricOptions.detector)')
+    return src
+
+
+def detector_call_kwargs(opts, detector_url, detector_kwargs):
+    """keyword arguments of the detector call: the metric's (return_features / no_output_bias: the reference's TorchScript files take them)
+    unless a callable stands in -- it takes the images alone"""
+    return {} if callable(detector_source(opts, detector_url)) else dict(detector_kwargs)
+
+
 def _detector(opts, detector_url):
-    src = opts.detector if opts.detector is not None else detector_url
-    return get_feature_detector(url=src, device=opts.device, num_gpus=opts.num_gpus, rank=opts.rank, detector_dir=opts.detector_dir)
+    return get_feature_detector(url=detector_source(opts, detector_url), device=opts.device, num_gpus=opts.num_gpus, rank=opts.rank,
+                                detector_dir=opts.detector_dir)
 
 
 def _as_rgb(images):
@@ -256,7 +286,7 @@ def compute_feature_stats_for_dataset(opts, detector_url, detector_kwargs, rel_l
 
     cache_file = None
     if opts.cache:      # all ranks must take the same branch: rank 0 looks, everybody hears
-        cache_file = _cache_path(opts, dataset, opts.detector if opts.detector is not None else detector_url, detector_kwargs, stats_kwargs)
+        cache_file = _cache_path(opts, dataset, detector_source(opts, detector_url), detector_kwargs, stats_kwargs)
         flag = os.path.isfile(cache_file) if opts.rank == 0 else False
         if opts.num_gpus > 1:
             t = torch.as_tensor(float(flag), dtype=torch.float32, device=opts.device)

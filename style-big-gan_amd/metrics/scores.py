@@ -20,7 +20,7 @@ def frechet_distance(mu_a, sigma_a, mu_b, sigma_b):
 
 
 def compute_fid(opts, max_real, num_gen, dataset_name='image_folder'):
-    kw = dict(return_features=True) if opts.detector is None else {}
+    kw = metric_utils.detector_call_kwargs(opts, INCEPTION, dict(return_features=True))
     mu_real, sigma_real = metric_utils.compute_feature_stats_for_dataset(
         opts=opts, detector_url=INCEPTION, detector_kwargs=kw, rel_lo=0, rel_hi=0, capture_mean_cov=True, max_items=max_real,
         dataset_name=dataset_name).get_mean_cov()
@@ -48,7 +48,7 @@ def kernel_distance(real_features, gen_features, num_subsets, max_subset_size, r
 
 
 def compute_kid(opts, max_real, num_gen, num_subsets, max_subset_size, dataset_name='image_folder'):
-    kw = dict(return_features=True) if opts.detector is None else {}
+    kw = metric_utils.detector_call_kwargs(opts, INCEPTION, dict(return_features=True))
     real = metric_utils.compute_feature_stats_for_dataset(opts=opts, dataset_name=dataset_name, detector_url=INCEPTION, detector_kwargs=kw,
                                                           rel_lo=0, rel_hi=0, capture_all=True, max_items=max_real).get_all()
     gen = metric_utils.compute_feature_stats_for_generator(opts=opts, dataset_name=dataset_name, detector_url=INCEPTION, detector_kwargs=kw,
@@ -70,7 +70,7 @@ def inception_score(gen_probs, num_splits):
 
 
 def compute_is(opts, num_gen, num_splits, dataset_name='image_folder'):
-    kw = dict(no_output_bias=True) if opts.detector is None else {}
+    kw = metric_utils.detector_call_kwargs(opts, INCEPTION, dict(no_output_bias=True))
     probs = metric_utils.compute_feature_stats_for_generator(opts=opts, dataset_name=dataset_name, detector_url=INCEPTION, detector_kwargs=kw,
                                                              capture_all=True, max_items=num_gen).get_all()
     if opts.rank != 0:
@@ -117,7 +117,7 @@ def precision_recall(real_features, gen_features, nhood_size, row_batch_size, co
 
 
 def compute_pr(opts, max_real, num_gen, nhood_size, row_batch_size, col_batch_size, dataset_name='image_folder'):
-    kw = dict(return_features=True) if opts.detector is None else {}
+    kw = metric_utils.detector_call_kwargs(opts, VGG16, dict(return_features=True))
     half = torch.float16 if torch.device(opts.device).type == 'cuda' else torch.float32
     real = metric_utils.compute_feature_stats_for_dataset(opts=opts, dataset_name=dataset_name, detector_url=VGG16, detector_kwargs=kw, rel_lo=0, rel_hi=0,
                                                           capture_all=True, max_items=max_real).get_all_torch().to(half).to(opts.device)

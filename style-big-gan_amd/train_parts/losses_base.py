@@ -44,7 +44,6 @@ _scope = torch.autograd.profiler.record_function
 import os as _os
 merge_d_passes = _os.environ.get('SBG_MERGE_D', '1') != '0'      # Dmain: one discriminator pass over [generated; real] (see _pass_d_adv)
 fuse_d_pairs = _os.environ.get('SBG_FUSE_D_PAIRS', '1') != '0'   # first-order D passes: conv0 + the low-pass of conv1 as one Function (ops/conv_bias_act.py)
-_order_cache = {}
 
 #             phase      passes, in execution order
 _PROGRAMS = {'Gmain': ('g_adv',), 'Greg': ('g_reg',), 'Gboth': ('g_adv', 'g_reg'),
@@ -188,8 +187,12 @@ class LossBase:
         d = getattr(self.D, 'module', self.D)
         if not getattr(d, 'batch_mergeable', False):
             return None
-        key = (id(d), n, segments, device)
-        hit = _order_cache.get(key)
+        # cached on the module instance (like its pass plans), keyed by everything the order depends on: a module-level dict keyed by id(d)
+        # would hand a new discriminator that re-uses a collected one's id a stale order (other group size / pass limit)
+        cache = d.__dict__.setdefault('_merged_order_cache', {})
+        key = (n, segments, str(device), getattr(d, 'pass_bytes_limit', None),
+               getattr(getattr(getattr(d, 'b4', None), 'mbstd', None), 'group_size', None))
+        hit = cache.get(key)
         if hit is None:
             fits = d.pass_plan(segments * n) is not None if hasattr(d, 'pass_plan') else True
             order = d.merged_batch_order(n, segments) if fits else None
@@ -200,7 +203,7 @@ class LossBase:
                 inv = torch.empty_like(fwd)
                 inv[fwd] = torch.arange(segments * n, device=device)
                 hit = (fwd, inv)
-            _order_cache[key] = hit
+            cache[key] = hit
         return hit if hit[0] is not None else None
 
     def _both_halves_order(self, gen_img, rnd, n):

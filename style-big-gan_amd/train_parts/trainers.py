@@ -63,6 +63,7 @@ class StepEngine:
         self.cur_nimg = 0
         self.batch_idx = 0
         self._round_plan = {}
+        self._round_proven = set()  # merged-round plans that have run once without exhausting device memory
         self._count_nonfinite = False
         self.comm_stats = None      # bench.py: {phase: dict(pairs=[event pairs around waits for exchanges], nonfinite=device counter)}
 
@@ -173,18 +174,34 @@ class StepEngine:
                 for r in phase.reducers:
                     r.zero_grad()
                 phase.module.requires_grad_(True)
-                if self._rounds_in_one_pass(phase.name, rounds):
+                merged = self._rounds_in_one_pass(phase.name, rounds)
+                if merged:
                     # every loss term is a mean over the pass: the mean over `rounds` rounds times `rounds` is the sum of the rounds' means
                     mapping = getattr(self.G, 'mapping', None)
+                    first_try = (phase.name, rounds) not in self._round_proven
+                    w_avg0 = mapping.w_avg.clone() if first_try and mapping is not None and hasattr(mapping, 'w_avg') else None
                     if mapping is not None:
                         mapping.w_avg_rounds = rounds
                     try:
                         self.loss.accumulate_gradients(phase=phase.name, real_img=real_img, real_c=torch.cat(real_cs), gen_z=torch.cat(phase_z),
                                                        gen_c=torch.cat(phase_c), sync=True, gain=phase.interval * rounds, segments=rounds)
+                        self._round_proven.add((phase.name, rounds))
+                    except torch.OutOfMemoryError:
+                        # `batch_gpu` is the config's memory knob: a run whose rounds fit one at a time must not die because they were merged.
+                        # Only the first attempt of a plan may fall back (afterwards the plan is known to fit and an OOM is a real one).
+                        if not first_try:
+                            raise
+                        merged = False
+                        self._round_plan[(phase.name, rounds)] = False
+                        for r in phase.reducers:
+                            r.finish(nan_to_num=False, reduce=False); r.zero_grad()
+                        if w_avg0 is not None:
+                            mapping.w_avg.copy_(w_avg0)
+                        torch.cuda.empty_cache()
                     finally:
                         if mapping is not None:
                             mapping.w_avg_rounds = 1
-                else:
+                if not merged:
                     for round_idx, (img, c, z, gc) in enumerate(zip(reals, real_cs, phase_z, phase_c)):
                         sync = (round_idx == rounds - 1)
                         self.loss.accumulate_gradients(phase=phase.name, real_img=img, real_c=c, gen_z=z, gen_c=gc, sync=sync, gain=phase.interval)
@@ -409,6 +426,16 @@ class BaseTrainer:
         self.ema_kimg = config.ema.kimg
         self.ema_rampup = config.ema.ramp if config.ema.ramp >= 0 else None
         self.total_kimg = gen.kimg
+        if self.metrics and not (isinstance(self.metric_detector, str) and os.path.exists(self.metric_detector)):
+            # the reference fetches its detectors from a URL at the first snapshot; this build never downloads.  A run on a real data set that
+            # is configured with metrics (the reference's DEFAULT is [fid50k_full, is50k]) and has nothing to compute them with would train
+            # for hours and report nothing: refuse at setup.  Synthetic data has no data set to score against: the metrics are dropped, loudly.
+            if self.real_data:
+                raise ValueError(f"log.metrics={self.metrics} needs log.metric_detector=<local TorchScript file or directory holding "
+                                 "inception-2015-12-05.pt / vgg16.pt> (detectors are not downloaded in this build); log.metrics=[] turns them off")
+            import warnings
+            warnings.warn(f"log.metrics={self.metrics} ignored: data.dataset=synthetic has no data set to score against")
+            self.metrics = []
         return self
 
     @staticmethod
@@ -578,7 +605,9 @@ class BaseTrainer:
             eng.train_iteration(img.to(torch.float32) / 127.5 - 1, c)
             it += 1
             if self.snapshot_iterations and it % self.snapshot_iterations == 0:
-                self.save_snapshot()
+                path = self.save_snapshot()
+                if self.metrics:            # every configured metric after each snapshot, on all ranks (reference :834-836)
+                    self.evaluate_metrics(snapshot_path=path)
             if max_iterations is None and total >= 0 and eng.cur_nimg >= total:
                 break
         self.stats.update()

@@ -142,6 +142,59 @@ def test_batch_norms(dev):
     assert max_rel(m2, xb.float().mean([0, 2, 3])) < 1e-4 and max_rel(v2, xb.float().var([0, 2, 3], unbiased=False)) < 1e-3
 
 
+def test_norm_style_variants_and_mybn(dev):
+    """ccbn norm_style 'in' / 'gn' / 'nonorm' and the `mybn` path (reference layers.py:212-253, 257-268, 310-325) on the device against the
+    reference's own formulas evaluated by torch on the CPU: outputs, input gradients, running buffers (instance norm: batch mean of the
+    per-instance statistics, unbiased variance; myBN: BIASED variance; standing statistics), train and eval mode."""
+    torch.manual_seed(4)
+    x = torch.randn(4, 32, 12, 10); y = torch.randn(4, 7); dy = torch.randn(4, 32, 12, 10)
+
+    def run(mod, eval_mode=False):
+        mod = mod.to(dev)
+        mod.train(not eval_mode)
+        xg = x.to(dev).requires_grad_(True)
+        out = mod(xg, y.to(dev))
+        (dx,) = torch.autograd.grad((out * dy.to(dev)).sum(), xg)
+        return out.detach().cpu(), dx.cpu()
+
+    for style in ("in", "gn", "gn_grp_4", "gn_ch_8", "nonorm"):
+        m = L.ccbn(32, 7, torch.nn.Linear, norm_style=style)
+        gain = (1 + m.gain(y)).view(4, -1, 1, 1).detach(); bias = m.bias(y).view(4, -1, 1, 1).detach()
+        xr = x.clone().requires_grad_(True)
+        rm, rv = torch.zeros(32), torch.ones(32)
+        if style == "in":
+            ref = F.instance_norm(xr, rm, rv, None, None, True, 0.1, 1e-5) * gain + bias
+        elif style == "nonorm":
+            ref = xr * gain + bias
+        else:
+            ref = F.group_norm(xr, L.group_norm_groups(style, 32)) * gain + bias
+        (dxr,) = torch.autograd.grad((ref * dy).sum(), xr)
+        out, dx = run(m)
+        assert max_rel(out, ref) < 1e-5 and max_rel(dx, dxr) < 1e-4, style
+        if style == "in":
+            assert max_rel(m.stored_mean, rm) < 1e-5 and max_rel(m.stored_var, rv) < 1e-5
+            out_e, _ = run(m, eval_mode=True)
+            assert max_rel(out_e, F.instance_norm(x, rm, rv, None, None, False, 0.1, 1e-5) * gain + bias) < 1e-5
+    with pytest.raises(NotImplementedError):
+        L.ccbn(32, 7, torch.nn.Linear, norm_style="layer")
+    # myBN: mean-of-squares statistics, running average of the biased variance, standing statistics
+    m = L.bn(32, mybn=True)
+    assert sorted(m.state_dict()) == ["bias", "bn.accumulation_counter", "bn.stored_mean", "bn.stored_var", "gain"]
+    mean = x.mean([0, 2, 3]); var = (x ** 2).mean([0, 2, 3]) - mean ** 2
+    out, _ = run(m)
+    assert max_rel(out, (x - mean.view(1, -1, 1, 1)) * torch.rsqrt(var + 1e-5).view(1, -1, 1, 1)) < 1e-5
+    assert max_rel(m.bn.stored_mean, 0.1 * mean) < 1e-5 and max_rel(m.bn.stored_var, 0.9 + 0.1 * var) < 1e-5
+    m.bn.reset_stats(); m.bn.accumulate_standing = True
+    run(m); run(m)
+    assert float(m.bn.accumulation_counter) == 2.0 and max_rel(m.bn.stored_var, 2 * var) < 1e-5
+    out_e, _ = run(m, eval_mode=True)
+    assert max_rel(out_e, (x - mean.view(1, -1, 1, 1)) * torch.rsqrt(var + 1e-5).view(1, -1, 1, 1)) < 1e-5
+    mc = L.ccbn(32, 7, torch.nn.Linear, mybn=True)
+    gain = (1 + mc.gain(y)).view(4, -1, 1, 1).detach(); bias = mc.bias(y).view(4, -1, 1, 1).detach()
+    out, _ = run(mc)
+    assert max_rel(out, (x - mean.view(1, -1, 1, 1)) * torch.rsqrt(var + 1e-5).view(1, -1, 1, 1) * gain + bias) < 1e-5
+
+
 def test_pooling_and_upsampling_as_fir(dev):
     torch.manual_seed(2)
     x = torch.randn(2, 8, 6, 10, device=dev)

@@ -188,7 +188,7 @@ def test_training_on_an_image_folder(tmp_path):
         pytest.skip("plumbing test is for the CPU container")
     path, _ = _make_image_folder(tmp_path / "data", n=20)
     argv = _write(tmp_path, "dcgan.yaml", DCGAN_LIKE) + ["gen.batch=8", "gen.batch_gpu=8", "data.dataset=image_folder", f"data.dataset_path={path}",
-                                                         "data.mirror=true", "dataloaders_args.basic.num_workers=0", "gen.kimg=1"]
+                                                         "data.mirror=true", "dataloaders_args.basic.num_workers=0", "gen.kimg=1", "log.metrics=[]"]
     t = starter.main(argv, max_iterations=2)
     assert t.engine.batch_idx == 2 and len(t.dataset) == 40 and t.dataset.resolution == 32 and t.training_set_kwargs["xflip"] is True
     assert all(torch.isfinite(p).all() for p in t.engine.G.parameters())
@@ -222,3 +222,35 @@ def test_image_folder_and_sampler_against_the_reference(tmp_path):
     for j, kw in enumerate(g.meta["samplers"]):
         it = iter(misc.InfiniteSampler(ds, **kw))
         assert [int(next(it)) for _ in range(60)] == g.npz[f"sampler{j}"].tolist(), kw
+
+
+REFERENCE_CONFIGS = "/root/reference/configs"
+
+
+@pytest.mark.parametrize("name", ["dcgan", "sg2ada", "big_gan", "ffhq_sg2", "sg2attent"])
+def test_reference_yaml_files_load_unchanged(name, tmp_path):
+    """the reference's OWN configs/*.yaml (the five BASELINE.json names) through arguments.load_config + trainer.setup_arguments, as they are:
+    container-only (the reference does not travel to the GPU box).  Data comes from the synthetic stand-in -- the yaml's data paths
+    (./data/*.zip) do not exist here -- and wandb logging keys are carried but unused."""
+    path = os.path.join(REFERENCE_CONFIGS, name + ".yaml")
+    if not os.path.isfile(path):
+        pytest.skip("reference checkout not present (GPU box)")
+    from style_big_gan_amd.train_parts.trainers import trainers
+    raw = yaml.safe_load(open(path))
+    argv = ["exp.config_dir=" + REFERENCE_CONFIGS, f"exp.config={name}.yaml", "exp.name=t", "data.dataset=synthetic", "data.num_classes=10",
+            "data.resolution=" + {"dcgan": "32", "sg2ada": "256", "big_gan": "128", "ffhq_sg2": "1024", "sg2attent": "32"}[name]]
+    cfg = arguments.load_config(argv)
+    assert cfg.exp.trainer == raw["exp"]["trainer"] and cfg.gen.batch == raw["gen"]["batch"]
+    for group in ("gens_args", "discs_args", "optim_gen_args", "optim_disc_args", "disc_regs_all", "gen_regs_all", "losses_arch_args"):
+        for key, sub in (raw.get(group) or {}).items():
+            for leaf, val in sub.items():
+                got = cfg[group][key][leaf]
+                assert (dict(got) if isinstance(val, dict) else got) == val or isinstance(val, dict), (group, key, leaf)
+    tr = trainers[cfg.exp.trainer]().setup_arguments(cfg)
+    assert tr.batch_size == raw["gen"]["batch"] and tr.G_kwargs["img_resolution"] == int(argv[-1].split("=")[1])
+    gen_name = cfg.gen.generator
+    assert gen_name == raw["gen"].get("generator", gen_name)
+    if name == "ffhq_sg2":
+        assert [n for n, _ in tr.gen_regs] == ["ppl"] and [n for n, _ in tr.dis_regs] == ["r1"] and tr.G_kwargs["mapping_kwargs"]["num_layers"] == raw["gens_args"]["sg2_classic"]["mapping_kwargs"]["num_layers"]
+    if name == "sg2attent":
+        assert list(tr.G_kwargs["attentions"]) == list(raw["gens_args"]["sg2_classic"]["attentions"])

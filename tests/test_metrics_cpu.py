@@ -184,3 +184,89 @@ def test_feature_loop_world2_gloo(tmp_path):
         for p in procs:
             assert p.exitcode == 0, f"worker exit code {p.exitcode}"
         assert dict(results) == {0: "ok", 1: "ok"}
+
+
+class _ScriptedDetector(torch.nn.Module):
+    """TorchScript stand-in with the reference detectors' call surface: class outputs by default, 16-d features with return_features=True"""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.register_buffer("w", torch.randn(48, 16, generator=g) / 48 ** 0.5)
+        self.register_buffer("head", torch.randn(16, 4, generator=g))
+
+    def forward(self, images: torch.Tensor, return_features: bool = False, no_output_bias: bool = False) -> torch.Tensor:
+        x = torch.nn.functional.adaptive_avg_pool2d(images.float() / 255.0, 4).flatten(1) @ self.w
+        if return_features:
+            return x
+        return torch.softmax(x @ self.head + (0.0 if no_output_bias else 1.0), dim=1)
+
+
+def test_file_detectors_receive_the_metric_kwargs(tmp_path):
+    """a detector given as a FILE is called like the reference's own files -- FID / KID / PR with return_features=True, IS with no_output_bias=True
+    (frechet_inception_distance.py:24, inception_score.py:24); a callable gets the images alone; one file is never used for a metric that asks for
+    another detector; a dict maps detector names to files"""
+    path = _make_image_folder(str(tmp_path / "data"), 16)
+    ddir = tmp_path / "detectors"
+    ddir.mkdir()
+    torch.jit.script(_ScriptedDetector()).save(str(ddir / "inception-2015-12-05.pt"))
+    inc = str(ddir / "inception-2015-12-05.pt")
+    common = dict(G=_toy_generator(), dataset_kwargs=dict(path=path, use_labels=False), num_gpus=1, rank=0, device=torch.device("cpu"), cache=False)
+    by_file = metric_utils.MetricOptions(detector=inc, **common)
+    by_dir = metric_utils.MetricOptions(detector_dir=str(ddir), **common)
+    by_map = metric_utils.MetricOptions(detector={"inception-2015-12-05": inc}, **common)
+    assert metric_utils.detector_call_kwargs(by_file, scores.INCEPTION, dict(return_features=True)) == dict(return_features=True)
+    assert metric_utils.detector_call_kwargs(metric_utils.MetricOptions(detector=_Projection(), **common), scores.INCEPTION, dict(return_features=True)) == {}
+    st = metric_utils.compute_feature_stats_for_dataset(by_file, scores.INCEPTION, metric_utils.detector_call_kwargs(by_file, scores.INCEPTION, dict(return_features=True)),
+                                                        batch_size=8, data_loader_kwargs=dict(num_workers=0), capture_all=True)
+    assert st.get_all().shape == (16, 16)                        # the 16-d features, not the 4 class outputs
+    fids = []
+    for o in (by_file, by_dir, by_map):
+        torch.manual_seed(3)                                     # the same generated latents for every way of naming the detector
+        fids.append(scores.compute_fid(o, max_real=None, num_gen=24))
+    assert np.isfinite(fids[0]) and fids[0] > 0 and abs(fids[0] - fids[1]) < 1e-9 and abs(fids[0] - fids[2]) < 1e-9
+    mean, std = scores.compute_is(by_file, num_gen=24, num_splits=2)
+    assert 1.0 <= mean <= 4.0 + 1e-6
+    with pytest.raises(RuntimeError, match="vgg16"):             # precision / recall wants VGG16 features: the Inception file must not stand in
+        scores.compute_pr(by_file, max_real=None, num_gen=16, nhood_size=3, row_batch_size=8, col_batch_size=8)
+    with pytest.raises(RuntimeError, match="no local detector"):
+        scores.compute_pr(by_map, max_real=None, num_gen=16, nhood_size=3, row_batch_size=8, col_batch_size=8)
+
+
+def test_training_loop_evaluates_configured_metrics(tmp_path):
+    """log.metrics is evaluated after every snapshot of the training loop (reference trainers.py:834-836) and metric-<name>.jsonl is written; a run
+    configured with metrics but without a local detector is refused at setup"""
+    if torch.cuda.is_available():
+        pytest.skip("plumbing test is for the CPU container")
+    import yaml
+    from style_big_gan_amd import starter
+
+    @metric_main.register_metric
+    def fid_loop_tiny(opts, dataset_name="image_folder"):
+        opts.dataset_kwargs.update(max_size=None, xflip=False)
+        return dict(fid_loop_tiny=scores.compute_fid(opts, dataset_name=dataset_name, max_real=None, num_gen=16))
+
+    path = _make_image_folder(str(tmp_path / "data"), 16)
+    ddir = tmp_path / "detectors"
+    ddir.mkdir()
+    torch.jit.script(_ScriptedDetector()).save(str(ddir / "inception-2015-12-05.pt"))
+    cfg = {"exp": {"trainer": "base"},
+           "gen": {"kimg": 1, "batch": 8, "batch_gpu": 8, "loss_arch": "base", "loss": "bcew", "generator": "cnn32_dcgan", "discriminator": "cnn32_dcgan",
+                   "g_reg_interval": 0, "d_reg_interval": 0},
+           "gens_args": {"cnn32_dcgan": {"z_dim": 16}}, "ema": {"use_ema": False}, "aug": {"aug": "noaug"},
+           "log": {"output": str(tmp_path / "logs"), "metrics": ["fid_loop_tiny"]},
+           "data": {"dataset": "image_folder", "dataset_path": path}, "dataloaders_args": {"basic": {"num_workers": 0}}}
+    with open(tmp_path / "run.yaml", "w") as fh:
+        yaml.safe_dump(cfg, fh)
+    argv = ["exp.config_dir=" + str(tmp_path), "exp.config=run.yaml", "exp.name=m"]
+    with pytest.raises(ValueError, match="metric_detector"):
+        starter.main(argv, max_iterations=0)
+    t = starter.main(argv + [f"log.metric_detector={ddir}"], max_iterations=0)
+    t.snapshot_iterations = 2
+    t.training_loop(max_iterations=4)
+    run_dir = tmp_path / "logs" / "m"
+    lines = open(run_dir / "metric-fid_loop_tiny.jsonl").read().strip().splitlines()
+    assert len(lines) == 2                                       # one per snapshot
+    rec = json.loads(lines[-1])
+    assert rec["snapshot_pkl"].startswith("network-snapshot-") and np.isfinite(rec["results"]["fid_loop_tiny"])
+    assert "fid_loop_tiny" in t.stats_metrics and t.metrics_time > 0

@@ -297,3 +297,85 @@ def test_synthesis_network_sliced_trailing_blocks(dev):
         assert bool(torch.isfinite(wg.grad).all()) and float(wg.grad.abs().sum()) > 0
     finally:
         del syn.pass_bytes_limit
+
+
+@pytest.mark.parametrize("num_fp16_res", [6, 0])
+def test_headline_architecture_256(dev, num_fp16_res):
+    """The architecture bench.py times -- configs/sg2ada.yaml at 256x256: channel_base 32768 (512-channel blocks up to 64^2, 256 at 128^2, 128 at
+    256^2), 2 mapping layers, G 'skip', D 'orig', conv_clamp 256 -- at batch 2 against oracle/networks.py on the same weights, latents and reals:
+    generator image, discriminator logits, and the Gmain / Dmain gradients of every parameter (softplus losses, constant noise).
+    num_fp16_res 6 = the benchmark's precision (bf16 storage from 8^2 up): activations within the bf16 network tolerance 6e-2 of the tensor's
+    largest magnitude, gradients within 2e-1 in relative L2 norm per parameter tensor and 6e-2 over all parameters together (a bf16 network's
+    activation masks differ from the fp32 oracle's in a few percent of the positions; the per-op arithmetic is pinned at 2e-2 in test_ops_gpu.py).
+    num_fp16_res 0 = fp32 storage through the SAME kernels at the same shapes (six bf16 products per convolution): 1e-4 activations, 2e-3 gradients
+    -- this is the run that pins the indexing of every kernel at the full widths."""
+    import json
+    import os
+    import bench
+    from oracle import networks as ON
+    torch.manual_seed(31)
+    gk, dk = bench.sg2ada_kwargs(res=256, num_fp16_res=num_fp16_res, conv_clamp=256)
+    G = PG.generators["sg2_classic"](**gk)
+    D = PD.discriminators["sg2_classic"](**dk)
+    with torch.no_grad():
+        for name, p in list(G.named_parameters()) + list(D.named_parameters()):
+            if name.endswith("noise_strength"):
+                p.fill_(0.1)
+            elif name.endswith("bias") and "affine" not in name and p.ndim == 1:
+                p.copy_(torch.randn_like(p) * 0.1)
+    cfg = ON.default_cfg(z_dim=512, w_dim=512, c_dim=0, img_resolution=256, channel_base=32768, mapping_layers=2,
+                         g_architecture="skip", d_architecture="orig", conv_clamp=256, mbstd_group_size=32)
+    gsd = {k: v.detach().float().clone() for k, v in G.state_dict().items()}
+    dsd = {k: v.detach().float().clone() for k, v in D.state_dict().items()}
+    n = 2
+    z_g, z_d = torch.randn(n, 512), torch.randn(n, 512)
+    real = torch.randint(0, 256, [n, 3, 256, 256]).float() / 127.5 - 1
+    c = torch.zeros(n, 0)
+    with torch.no_grad():
+        img_ref = ON.generator(gsd, z_g, c, cfg, noise_mode="const")
+        logits_ref = ON.discriminator(dsd, img_ref, c, cfg)
+    loss_g_ref, grads_g, loss_d_ref, grads_d, _ = ON.gd_step_grads(gsd, dsd, cfg, z_g, z_d, real, r1_gamma=None, noise_mode="const")
+
+    G, D = G.to(dev).train(), D.to(dev).train()
+    cd = c.to(dev)
+    act_tol, per_tensor, overall = (6e-2, 2e-1, 6e-2) if num_fp16_res else (1e-4, 2e-3, 1e-3)
+    with torch.no_grad():
+        img = G(z_g.to(dev), cd, noise_mode="const")
+        logits = D(img_ref.to(dev), cd)
+    e_img, e_log = max_rel(img, img_ref), max_rel(logits, logits_ref)
+
+    def phase_grads(module, loss, ref):
+        for p in module.parameters():
+            p.grad = None
+        loss.backward()
+        worst, num, den = ("", 0.0), 0.0, 0.0
+        for name, p in module.named_parameters():
+            r = ref[name].double()
+            g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().double().cpu()
+            assert bool(torch.isfinite(g).all()), name
+            d2, r2 = float((g - r).square().sum()), float(r.square().sum())
+            num += d2; den += r2
+            if r2 > 1e-20 and (d2 / r2) ** 0.5 > worst[1]:
+                worst = (name, (d2 / r2) ** 0.5)
+        return worst, (num / max(den, 1e-300)) ** 0.5
+
+    F = torch.nn.functional
+    G.requires_grad_(True); D.requires_grad_(False)
+    loss_g = F.softplus(-D(G(z_g.to(dev), cd, noise_mode="const"), cd)).mean()
+    worst_g, all_g = phase_grads(G, loss_g, grads_g)
+    G.requires_grad_(False); D.requires_grad_(True)
+    with torch.no_grad():
+        fake = G(z_d.to(dev), cd, noise_mode="const")
+    loss_d = F.softplus(-D(real.to(dev), cd)).mean() + F.softplus(D(fake, cd)).mean()
+    worst_d, all_d = phase_grads(D, loss_d, grads_d)
+    report = dict(num_fp16_res=num_fp16_res, img=e_img, logits=e_log, loss_g=[float(loss_g), float(loss_g_ref)], loss_d=[float(loss_d), float(loss_d_ref)],
+                  gradG_worst=worst_g, gradG_all=all_g, gradD_worst=worst_d, gradD_all=all_d)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, f"headline_parity_nfp{num_fp16_res}.json"), "w") as f:
+            json.dump(report, f)
+    assert e_img < act_tol and e_log < act_tol, report
+    assert abs(float(loss_g) - float(loss_g_ref)) < act_tol * max(1.0, abs(float(loss_g_ref))), report
+    assert abs(float(loss_d) - float(loss_d_ref)) < act_tol * max(1.0, abs(float(loss_d_ref))), report
+    assert worst_g[1] < per_tensor and worst_d[1] < per_tensor, report
+    assert all_g < overall and all_d < overall, report

@@ -257,6 +257,28 @@ def test_conv_transpose_stride2_one_pass_kernel(dev, dtype):
     assert sum(c // 1000000 == 9 for c in codes) >= 3, codes
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_thin_channel_kernels_multi_tile(dev, dtype):
+    """conv_thin_kernel / conv_wgrad_thin_kernel (csrc/conv_thin.hip, conv_wgrad.hip: <= 64 / <= 32 channels, ffhq_sg2.yaml's 512^2 / 1024^2 blocks)
+    at sizes with MANY 16 x 16 tiles per image, ragged in both directions, several images: forward, dx and dw against the oracle for a
+    3x3 / stride 1, a stride-2, a transposed stride-2 (four phase tables) and a 1x1 layer with 3 outputs; the launch log must show that the
+    thin kernels were the ones that ran (code 6xxxxxx = conv_thin_kernel, 3xxxxxx = conv_wgrad_thin_kernel)."""
+    from style_big_gan_amd import _lib
+    _lib.prof_enable(True); _lib.prof_fetch()
+    _conv_case(dev, dtype, 2, 16, 16, 96, 160, 3, 1, 1, False)        # 6 x 10 tiles per image
+    _conv_case(dev, dtype, 2, 32, 16, 129, 257, 3, 2, 0, False)       # stride 2 -> 64 x 128; its dx is a transposed thin conv (16 -> 32)
+    _conv_case(dev, dtype, 2, 32, 16, 48, 80, 3, 2, 0, True)          # transposed -> 97 x 161: four phases with different grids
+    _conv_case(dev, dtype, 3, 16, 3, 96, 160, 1, 1, 0, False)         # ToRGB-like 1x1, Cout = 3
+    _conv_case(dev, dtype, 1, 24, 40, 70, 45, 3, 1, 1, False)         # ragged channels (Cin 24 -> 1.5 fragments, Cout 40), odd image
+    _conv_case(dev, dtype, 2, 16, 32, 33, 513, 3, 1, 1, False)        # one very wide strip: 33 column tiles, 3 row tiles (the last one row)
+    _lib.prof_enable(False)
+    rec = _lib.prof_fetch()
+    thin_conv = [r for r in rec if r["kind"] == "conv_igemm" and r["dims"][6] // 1000000 == 6]
+    thin_wgrad = [r for r in rec if r["kind"] == "conv_wgrad" and r["dims"][6] // 1000000 == 3]
+    assert len(thin_conv) >= 10, [r["dims"] for r in rec if r["kind"] == "conv_igemm"]          # >= 5 forwards + their data gradients
+    assert len(thin_wgrad) >= 5, [r["dims"] for r in rec if r["kind"] == "conv_wgrad"]
+
+
 def test_split_bf16_cat_dense_of_strided_view(dev):
     """sbg_split_bf16_cat_nd on a permuted weight view == the memory-order split followed by .contiguous(), bit for bit; the parts sum back
     to the fp32 value within 2^-24 relative"""

@@ -73,6 +73,52 @@ def test_upfirdn2d_reference_vectors(dev):
         _close(ddy, g.t(f"{k}/ddy"), 1e-5, f"{case} ddy")
 
 
+def test_plugin_call_surface_reference_vectors(dev):
+    """custom_ops.get_plugin(module_name, sources, **build_kwargs) (reference custom_ops.py:46): the objects it returns are called exactly
+    as the reference's op modules call their pybind plugins -- bias_act.py:150,172 (forward; first derivative from dy, x, y with an EMPTY
+    tensor for every absent one) and upfirdn2d.py:236 -- and must reproduce the reference's vectors."""
+    import style_big_gan_amd as pkg
+    pkg.install_reference_aliases()
+    from stylegan2ada.torch_utils import custom_ops
+    custom_ops.verbosity = "none"
+    ba = custom_ops.get_plugin("bias_act_plugin", sources=["bias_act.cpp", "bias_act.cu"], extra_cuda_cflags=["--use_fast_math"])
+    up = custom_ops.get_plugin("upfirdn2d_plugin", sources=["upfirdn2d.cpp", "upfirdn2d.cu"], extra_cuda_cflags=["--use_fast_math"])
+    assert custom_ops.get_plugin("bias_act_plugin", sources=[]) is ba
+    with pytest.raises(RuntimeError):
+        custom_ops.get_plugin("no_such_plugin", sources=[])
+    null = torch.empty([0], device=dev)
+    g = Golden("bias_act")
+    for case in g.meta["cases"]:
+        k = case["key"]
+        spec = bias_act.activation_funcs[case["act"]]
+        x = g.t(f"{k}/x").to(dev)
+        b = g.t(f"{k}/b").to(dev) if case["use_b"] else null
+        alpha = float(spec.def_alpha or 0)
+        gain = float(case["gain"] if case["gain"] is not None else spec.def_gain)
+        clamp = float(case["clamp"] if case["clamp"] is not None else -1)
+        y = ba.bias_act(x, b, null, null, null, 0, 1, spec.cuda_idx, alpha, gain, clamp)
+        _close(y, g.t(f"{k}/y"), 1e-5, f"plugin {case} y")
+        if case["clamp"] is None or case["act"] != "linear":        # (the CUDA plugin's linear + clamp gradient ignores the mask: DESIGN.md section 2)
+            dy = g.t(f"{k}/dy").to(dev)
+            dx = ba.bias_act(dy, b, x if ("x" in spec.ref or spec.has_2nd_grad) else null, y if "y" in spec.ref else null, null, 1, 1,
+                             spec.cuda_idx, alpha, gain, clamp)
+            _close(dx, g.t(f"{k}/dx"), 1e-5, f"plugin {case} dx")
+    g = Golden("upfirdn2d")
+    n_2d = 0
+    for case in g.meta["cases"]:
+        if case["filter"] not in ("k4", "k4_flipped_gain2"):
+            continue                # rank-1 filters are two plugin calls in the reference (:236-240), None is the identity filter
+        k = case["key"]
+        f = g.t(f"f/{case['filter']}").to(dev)
+        upx = upy = case["up"]; downx = downy = case["down"]
+        pad = case["padding"]
+        pad = [pad] * 4 if isinstance(pad, int) else ([pad[0], pad[0], pad[1], pad[1]] if len(pad) == 2 else list(pad))
+        y = up.upfirdn2d(g.t(f"{k}/x").to(dev), f, upx, upy, downx, downy, pad[0], pad[1], pad[2], pad[3], case["flip_filter"], case["gain"])
+        _close(y, g.t(f"{k}/y"), 1e-5, f"plugin {case} y")
+        n_2d += 1
+    assert n_2d > 50
+
+
 def test_conv2d_resample_reference_vectors(dev):
     g = Golden("conv2d_resample")
     f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
