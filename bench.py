@@ -212,7 +212,7 @@ def cpu_baseline(res=RES, budget_s=60.0):
     cores = host_cores()
     cands = [(1, cores, 2)]
     k = 2
-    while cores // k >= 2 and k <= 8:
+    while cores // k >= 2 and k <= 4:           # at most 4 workers: a GPU box admits 6 processes with the device open, and the workers' imports open it
         cands.append((k, cores // k, 2)); k *= 2
     t_start, best, tried, last = time.perf_counter(), None, [], 0.0
     for procs, threads, batch in cands:

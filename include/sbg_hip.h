@@ -382,6 +382,9 @@ typedef struct sbg_prof_record {
     float  ms;              /* measured duration */
     int    pad;
 } sbg_prof_record;
+/* Experiment word (diagnosis, not part of the contract): kernel variants under A/B test select on its bits; initial value from the
+ * environment variable SBG_EXPERIMENT; returns the previous value.  0 = the shipped configuration. */
+int sbg_experiment_set(int value);
 int sbg_prof_enable(int on);
 int sbg_prof_fetch(sbg_prof_record* out, int max);
 

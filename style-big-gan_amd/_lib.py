@@ -154,6 +154,7 @@ SYMBOLS = [
     ("sbg_grid_sample2d_bwd_overwrites", _c.c_int, [_c.POINTER(GridSampleParams)]),
     ("sbg_color_transform", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_filter1d_batch", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int] * 8 + [_c.c_void_p]),
+    ("sbg_experiment_set", _c.c_int, [_c.c_int]),
     ("sbg_prof_enable", _c.c_int, [_c.c_int]),
     ("sbg_prof_fetch", _c.c_int, [_c.POINTER(ProfRecord), _c.c_int]),
 ]

@@ -437,11 +437,11 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         // ---------------------------------------------------------------- halo loader (waves 10, 11) ----------------------
         const int lh = wave - 10;
         __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
-        auto issue_halo = [&](const TileC& tc, int chunk, int buf) {
+        auto issue_halo = [&](const TileC& tc, int chunk, int buf, int lo, int hi) {
             const unsigned okc = 0u - (unsigned)(chunk * 64 + src_k < p.Cin);
             const unsigned img = (unsigned)(tc.tn * (int)p.xs_n + chunk * 64 + src_k) * 2u;
 #pragma unroll 2
-            for (int i = 0; i < HPL; i++) {
+            for (int i = lo; i < hi; i++) {
                 const int piece = lh * HPL + i;
                 if (piece >= HPIECES) break;
                 const int pp = piece * 8 + lrow;
@@ -455,16 +455,28 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         };
         int tile = bid, chunk = 0;
         TileC tc = decode(tile);
-        issue_halo(tc, 0, 0);
+        issue_halo(tc, 0, 0, 0, HPL);
+        // The 22 pieces of the next slice go out TWO per half-step (behind each of the slice's first eleven barriers), not as one burst behind
+        // the first: an LDS-DMA instruction costs its wave ~100+ cycles beside the compute waves' fragment reads, every wave of the workgroup
+        // meets at the next barrier, and a burst of 22 made that one half-step ~4x as long as the 32 MFMAs it should hide behind.  Measured
+        // (scratch/kbench_ab.py, interleaved rounds on one device, [64, C, R, R] (*) [C, C, 3, 3]): C = 128 @ 256^2 1070 -> 1160 TF,
+        // 256 @ 128^2 1154 -> 1300, 512 @ 64^2 1214 -> 1389, 512 @ 32^2 1273 -> 1390; three or four per half-step 1090-1110 / 1220-1250 /
+        // 1280-1310.  Experiment bit 2 restores the burst.
+        const bool spread = !((p.debug >> 8) & 2);
+        const int per = 2;                               // pieces per half-step
         for (int c = 0; c < nslices; c++) {
             wait_vmcnt_const<0>();                       // halo(c) has landed
             __builtin_amdgcn_s_barrier();                // 18c
-            if (c + 1 < nslices && !(dbg & 2) && !(dbg & 32)) {       // 32: halo loads only
+            const bool more = c + 1 < nslices && !(dbg & 2) && !(dbg & 32);       // 32: halo loads only
+            if (more) {
                 if (++chunk == kchunks) { chunk = 0; tile += G; tc = decode(tile); }
-                issue_halo(tc, chunk, (c + 1) & 1);
+                if (!spread) issue_halo(tc, chunk, (c + 1) & 1, 0, HPL);
             }
 #pragma unroll
-            for (int i = 0; i < 17; i++) __builtin_amdgcn_s_barrier();
+            for (int i = 0; i < 17; i++) {
+                if (spread && more && per * i < HPL) issue_halo(tc, chunk, (c + 1) & 1, per * i, per * i + per < HPL ? per * i + per : HPL);
+                __builtin_amdgcn_s_barrier();
+            }
         }
         __builtin_amdgcn_s_barrier();                    // 2S
         return;
@@ -486,22 +498,30 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         // (it, ichunk, itile, istage): coordinates of the step whose weights are issued next
         int it = 0, ichunk = 0, itile = bid, istage = 0;
         weight_rows(decode(itile).c0);
-        auto issue_next = [&]() {
-            unsigned char* st = smem + istage * STAGE + lw * WPIECES * 1024;
-            const unsigned kokm = 0u - (unsigned)(ichunk * 64 + src_k < p.Cin);
-            const unsigned wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, it) + ichunk * 128);
+        unsigned char* st = nullptr; unsigned kokm = 0, wtap = 0;
+        auto issue_prep = [&]() {
+            st = smem + istage * STAGE + lw * WPIECES * 1024;
+            kokm = 0u - (unsigned)(ichunk * 64 + src_k < p.Cin);
+            wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, it) + ichunk * 128);
+        };
+        auto issue_part = [&](int lo, int hi) {
 #pragma unroll
             for (int i = 0; i < WPIECES; i++) {
+                if (i < lo || i >= hi) continue;
                 const unsigned okm = kokm & (0u - (unsigned)(a_base[i] != SBG_OOB_OFFSET));
                 const unsigned off = ((a_base[i] + wtap) & okm) | (SBG_OOB_OFFSET & ~okm);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + i * 1024), 16, off, 0, 0, 0);
             }
+        };
+        auto issue_done = [&]() {
             istage = (istage + 1) & (NSTAGE - 1);
             if (++it == NT) {
                 it = 0;
                 if (++ichunk == kchunks) { ichunk = 0; itile += G; if (itile < ntiles) weight_rows(decode(itile).c0); }
             }
         };
+        auto issue_next = [&]() { issue_prep(); issue_part(0, WPIECES); issue_done(); };
+        const bool split = (p.debug >> 8) & 1;           // experiment (off): half of a step's pieces behind each of its two barriers -- +2..4 % alone, -1 % beside the spread halo loads
         const int S = nslices * NT;
         int issued = 0;                                  // steps issued so far
         for (; issued < 4 && issued < S; issued++) issue_next();
@@ -513,9 +533,11 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             else if (newer == 1) wait_vmcnt_const<1 * WPIECES>();
             else wait_vmcnt_const<0>();
             __builtin_amdgcn_s_barrier();                // 2s
-            if (s >= 1 && issued < S && !(dbg & 2) && !(dbg & 16)) { issue_next(); issued++; }     // step s + 3 -> the stage step s - 1 was read from (16: weight loads only)
-            else if (s >= 1 && issued < S) issued++;
+            const bool go = s >= 1 && issued < S && !(dbg & 2) && !(dbg & 16);      // step s + 3 -> the stage step s - 1 was read from (16: weight loads only)
+            if (go) { issue_prep(); issue_part(0, split ? WPIECES / 2 : WPIECES); }
             __builtin_amdgcn_s_barrier();                // 2s + 1
+            if (go) { if (split) issue_part(WPIECES / 2, WPIECES); issue_done(); issued++; }
+            else if (s >= 1 && issued < S) issued++;
         }
         __builtin_amdgcn_s_barrier();                    // 2S
         return;
@@ -683,13 +705,15 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
         // (it, ic, itile, istage): coordinates of the step whose loads are issued next
         int it = 0, ic = 0, itile = bid, istage = 0;
         tile_state(itile);
-        auto issue_next = [&]() {
+        // the loads of one step in two parts (half = 0, 1; half < 0: everything): the two halves go behind the step's two barriers
+        auto issue_part = [&](int half) {
             const unsigned kokm = 0u - (unsigned)(ic * 64 + src_k < p.Cin);
             if (!xload) {
                 unsigned char* st = smem + istage * STAGE + lw * WPIECES * 1024;
                 const unsigned wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, ph_t0 + it) + ic * 128);
 #pragma unroll
                 for (int i = 0; i < WPIECES; i++) {
+                    if (half >= 0 && (i >= WPIECES / 2) != (half == 1)) continue;
                     const unsigned okm = kokm & (0u - (unsigned)(a_base[i] != SBG_OOB_OFFSET));      // branch-free: a masked-off lane would leave stale LDS bytes
                     const unsigned off = ((a_base[i] + wtap) & okm) | (SBG_OOB_OFFSET & ~okm);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + i * 1024), 16, off, 0, 0, 0);
@@ -699,6 +723,7 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
                 const int dy = __builtin_amdgcn_readlane(tbl_dy, ph_t0 + it), dx = __builtin_amdgcn_readlane(tbl_dx, ph_t0 + it);
 #pragma unroll
                 for (int i = 0; i < XPIECES; i++) {
+                    if (half >= 0 && (i >= XPIECES / 2) != (half == 1)) continue;
                     const int iy = b_iy0[i] + dy, ix = b_ix0[i] + dx;
                     const unsigned okm = kokm & (0u - (unsigned)(((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW)));
                     const unsigned real = b_base[i] + (unsigned)(iy * (int)p.xs_h + ix * (int)p.xs_w + ic * 64) * 2u;
@@ -706,12 +731,16 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(st + i * 1024), 16, off, 0, 0, 0);
                 }
             }
+        };
+        auto issue_done = [&]() {
             istage = istage == NSTAGE - 1 ? 0 : istage + 1;
             if (++ic == kchunks) {
                 ic = 0;
                 if (++it == ph_nt) { it = 0; itile += G; if (itile < ntiles) tile_state(itile); }
             }
         };
+        auto issue_next = [&]() { issue_part(-1); issue_done(); };
+        const bool split = !((p.debug >> 8) & 4);        // half of a step's pieces behind each of its two barriers (+0.5..1 %; experiment bit 4: all behind the first)
         int issued = 0;                                  // steps issued so far
         for (; issued < NSTAGE && issued < S; issued++) issue_next();
         for (int s = 0; s < S; s++) {
@@ -723,8 +752,10 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
                 if (newer >= 2) wait_vmcnt_const<2 * WPIECES>(); else if (newer == 1) wait_vmcnt_const<WPIECES>(); else wait_vmcnt_const<0>();
             }
             __builtin_amdgcn_s_barrier();                // 2s
-            if (s >= 1 && issued < S) { issue_next(); issued++; }     // step s + 2 -> the stage step s - 1 was read from
+            const bool go = s >= 1 && issued < S;        // step s + 2 -> the stage step s - 1 was read from
+            if (go) issue_part(split ? 0 : -1);
             __builtin_amdgcn_s_barrier();                // 2s + 1
+            if (go) { if (split) issue_part(1); issue_done(); issued++; }
         }
         __builtin_amdgcn_s_barrier();                    // 2S
         return;
@@ -975,8 +1006,9 @@ int sbg_conv_k64_dispatch(ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_byt
     const int level = e1 ? atoi(e1) : 2;
     if (level <= 0) return -1;
 #ifdef SBG_K64_DEBUG
-    { const char* e3 = sbg_env("SBG_K64_ABL"); a.debug = e3 ? atoi(e3) : 0; }
+    { const char* e3 = sbg_env("SBG_K64_ABL"); a.debug = (a.debug & ~255) | (e3 ? atoi(e3) & 255 : 0); }
 #endif
+    a.debug = (a.debug & 255) | (sbg_experiment() << 8);      // variants under A/B test (sbg_experiment_set)
     const unsigned xb = (unsigned)x_bytes, wb = (unsigned)w_bytes;
     const int64_t y_numel = (int64_t)a.P * a.Cout;
     const bool dense_y = a.ys_w == a.Cout && a.ys_h == (int64_t)a.OW * a.Cout && a.ys_n == (int64_t)a.OH * a.OW * a.Cout;

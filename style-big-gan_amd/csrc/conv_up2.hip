@@ -123,9 +123,8 @@ __global__ __launch_bounds__(512) void conv_up2_kernel(ConvArgs p, unsigned x_by
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(smem + lds_off), 16, ((src + (unsigned)chunk * 128u) & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
     };
     // the two weight pieces of step (chunk, k): taps 2k, 2k + 1 (k == 4: tap 8 and a spare)
-    auto dma_w = [&](int chunk, int k, int slot, bool live) {
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
+    auto dma_w_piece = [&](int chunk, int k, int slot, bool live, int e) {
+        {
             const int t = 2 * k + e;
             const bool ok = live & (t < 9) & (wrow != SBG_OOB_OFFSET) & (chunk * 64 + src_k < p.Cin);
             const unsigned okm = 0u - (unsigned)ok;
@@ -134,6 +133,12 @@ __global__ __launch_bounds__(512) void conv_up2_kernel(ConvArgs p, unsigned x_by
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)dst, 16, (off & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
         }
     };
+    auto dma_w = [&](int chunk, int k, int slot, bool live) { dma_w_piece(chunk, k, slot, live, 0); dma_w_piece(chunk, k, slot, live, 1); };
+    // `late`: a step's four DMA instructions go out one behind each group of eight MFMAs, not together in front of the step's first fragment
+    // read: all eight waves leave the barrier together, so four back-to-back LDS-DMA issues (~100 cycles each) kept the matrix pipe idle at the
+    // head of every step.  Measured (scratch/kbench_ab.py, one device, interleaved): [64,256,128^2] -> 128 725 -> 781 TF, [64,512,64^2] -> 256
+    // 841 -> 936, [64,512,32^2] -> 512 826 -> 918 (border launch included).  Experiment bit 8 restores the early issue.
+    const bool late = !((p.debug >> 8) & 8);
 
     // ---- prologue: halo of slice 0 (five slots per wave), weights of steps 0, 1, 2
 #pragma unroll
@@ -179,18 +184,17 @@ __global__ __launch_bounds__(512) void conv_up2_kernel(ConvArgs p, unsigned x_by
             constexpr int allowed = (k == 0) ? 4 : (k == 1) ? 6 : (k == 2) ? 8 : (k == 3) ? 8 : 6;
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(allowed) : "memory");
             __builtin_amdgcn_s_barrier();
-            // ---- loads: [halo pieces of slice c + 1 -> the other buffer] [weights of step s + 3 -> the slot step s - 1 used]
-            if constexpr (k < 3) {
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int q = 16 * k + 2 * wave + e;
-                    const bool live = (c + 1 < kchunks) & (q < HPIECES);
-                    dma_x(live ? halo_src(q) : SBG_OOB_OFFSET, c + 1, live ? (unsigned)(((c + 1) & 1) * HALO + q * 1024) : (unsigned)DUMP);
-                }
-            }
-            {
-                constexpr int k3 = (k + LEAD) % NSTEP;
-                const int c3 = c + (k + LEAD) / NSTEP;
+            // ---- loads: [halo pieces of slice c + 1 -> the other buffer] [weights of step s + 3 -> the slot step s - 1 used].  `late`: one
+            // DMA instruction behind each group of eight MFMAs instead of all four in front of the step's first fragment read (experiment)
+            auto dma_halo_piece = [&](int e) {
+                const int q = 16 * k + 2 * wave + e;
+                const bool live = (c + 1 < kchunks) & (q < HPIECES);
+                dma_x(live ? halo_src(q) : SBG_OOB_OFFSET, c + 1, live ? (unsigned)(((c + 1) & 1) * HALO + q * 1024) : (unsigned)DUMP);
+            };
+            constexpr int k3 = (k + LEAD) % NSTEP;
+            const int c3 = c + (k + LEAD) / NSTEP;
+            if (!late) {
+                if constexpr (k < 3) { dma_halo_piece(0); dma_halo_piece(1); }
                 dma_w(c3, k3, (slot + LEAD) & (NRING - 1), c3 < kchunks);
             }
             // ---- this step's taps
@@ -219,6 +223,17 @@ __global__ __launch_bounds__(512) void conv_up2_kernel(ConvArgs p, unsigned x_by
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) acc[ph][i][j] = Mfma<MF>::run(fa[buf][i], fb[buf][j], acc[ph][i][j]);
+                if (late) {
+                    // group g of NG carries DMA instructions [g * 4 / NG, (g + 1) * 4 / NG) of the step's four: weight piece 0, 1, halo piece 0, 1
+                    constexpr int d0 = g * 4 / NG, d1 = (g + 1) * 4 / NG;
+                    sbg_static_for<4>([&](auto dt) {
+                        constexpr int d = decltype(dt)::value;
+                        if constexpr (d >= d0 && d < d1) {
+                            if constexpr (d < 2) dma_w_piece(c3, k3, (slot + LEAD) & (NRING - 1), c3 < kchunks, d);
+                            else if constexpr (k < 3) dma_halo_piece(d - 2);
+                        }
+                    });
+                }
             });
             slot = (slot + 1) & (NRING - 1);
         });

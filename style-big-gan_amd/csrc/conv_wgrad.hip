@@ -48,6 +48,7 @@ struct WgradArgs {
     int atiles, btiles;
     int tap0;               // first tap handled by this launch (out slab offset)
     int ntaps_total;
+    int experiment;         // sbg_experiment() at launch: variants under A/B test
 };
 
 // Workgroup -> (a tile, b tile, pixel split).  Workgroups are dealt round-robin to the eight XCDs, each with its own L2: all channel
@@ -276,14 +277,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
     const int drow = lane >> 3, dchunk = lane & 7;
     auto src_chunk = [&](int R) { return (((dchunk >> 1) ^ ((R >> 1) & 3)) << 1) | (dchunk & 1); };   // swizzled source chunk for LDS row R
 
-    auto issue = [&](int loc) {
+    // coordinates of chunk `loc` (wave-uniform), then its DMA pieces i = 0 .. PIECES - 1 of this wave
+    struct ChunkC { int py, n, px0; unsigned char* st; };
+    auto chunk_coords = [&](int loc) -> ChunkC {
         const int c = chunk_begin + loc;
         const int xb = c % xblocks, rowid = c / xblocks;
-        const int py = rowid % p.PH, n = rowid / p.PH;
-        const int px0 = xb << 5;
-        unsigned char* st = smem + (loc % NSTAGE) * STAGE;
-#pragma unroll
-        for (int i = 0; i < PIECES; i++) {
+        ChunkC r; r.py = rowid % p.PH; r.n = rowid / p.PH; r.px0 = xb << 5; r.st = smem + (loc % NSTAGE) * STAGE;
+        return r;
+    };
+    auto issue_piece = [&](const ChunkC& cc, int i) {
+        const int py = cc.py, n = cc.n, px0 = cc.px0;
+        unsigned char* st = cc.st;
+        {
             const int piece = wave + NWAVE * i;                // wave-uniform
             if (piece < APIECES) {                             // a sub-tile piece >> 2, pixel rows 8 * (piece & 3) ..
                 const int R = (piece & 3) * 8 + drow;
@@ -310,6 +315,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
             }
         }
     };
+    auto issue = [&](int loc) {
+        const ChunkC cc = chunk_coords(loc);
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) issue_piece(cc, i);
+    };
+    // `late`: the DMA instructions of chunk s + DEPTH go out spread over the tap loop, each behind a tap's MFMAs, instead of together right
+    // behind the barrier (where all eight waves issued them at once and the matrix pipe waited).  Measured (scratch/kbench_ab.py, one device,
+    // interleaved rounds, 64 images): 128 x 128 @ 256^2 1060 -> 1135 TF, 256 x 256 @ 128^2 1149 -> 1227, 512 x 512 @ 64^2 1204 -> 1285,
+    // stride 2: 256 x 128 917 -> 1016, 512 x 256 966 -> 1081.  Experiment bit 16 restores the early issue.
+    const bool late = !(p.experiment & 16);
 
     const int wa = (wave >> 2) * (BCA / 2), wb = (wave & 3) * 16;
     const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;
@@ -357,8 +372,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
             else                                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (!(ABL & 2))
-            if (s + DEPTH < nloc) issue(s + DEPTH);
+        const bool more = !(ABL & 2) && s + DEPTH < nloc;
+        ChunkC nxt = chunk_coords(more ? s + DEPTH : s);
+        if (more && !late) {
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) issue_piece(nxt, i);
+        }
         // The transposing reads are issued as inline assembly with hand-counted lgkmcnt waits.  Written with the builtin, the compiler sees LDS
         // reads behind LDS-DMA writes it cannot tell apart and guards the first read of every chunk with s_waitcnt vmcnt(0) -- the wave then
         // waits for the loads it has just issued for chunk s + DEPTH, and the whole L2 -> LDS stream is exposed (ablation: 806 us, 532 us
@@ -401,6 +420,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
             for (int i = 0; i < TA; i++) {
                 const short8_t fa_i = short8_t{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]};
                 if constexpr ((ABL & 1) == 0) acc[t][i] = Mfma<MF>::run(fa_i, fb, acc[t][i]);
+            }
+            if (more && late) {      // pieces i with i * 9 / PIECES == t: spread evenly over the nine taps
+                sbg_static_for<PIECES>([&](auto pt) {
+                    constexpr int i = decltype(pt)::value;
+                    if constexpr (i * 9 / PIECES == t) issue_piece(nxt, i);
+                });
             }
         });
     }
@@ -635,7 +660,7 @@ static int fill_args(const sbg_wgrad_params* q, WgradArgs& a)
     a.stride = q->stride; a.ntaps = q->ntaps; a.accumulate = q->accumulate;
     for (int t = 0; t < SBG_MAX_TAPS; t++) { a.tap_dy[t] = q->tap_dy[t]; a.tap_dx[t] = q->tap_dx[t]; }
     a.P = (int64_t)q->N * q->PH * q->PW;
-    a.tap0 = 0; a.ntaps_total = q->ntaps;
+    a.tap0 = 0; a.ntaps_total = q->ntaps; a.experiment = sbg_experiment();
     if (use_big_tile(q->ntaps)) plan_split(a, 128, 128); else plan_split(a, 64, 64);
     if (rows_kernel_ok(q, a)) plan_split_target(a, rows_bca(a), 64, 512);      // one resident workgroup per CU: two waves of workgroups, half the slab traffic
     const ThinPlan tp = thin_plan(q);

@@ -47,6 +47,7 @@ bool sbg_launch_geometry_ok(dim3 grid, dim3 block, size_t lds_bytes, const char*
 
 // Experiment switches (SBG_* environment variables) are read once per process, never on the launch path.
 const char* sbg_env(const char* name);      // cached getenv: the first call per name scans `environ`, later calls are a table lookup
+int sbg_experiment();                       // experiment word (SBG_EXPERIMENT / sbg_experiment_set): kernel variants under A/B test select on its bits
 
 // ------------------------------------------------------------------------------------------------
 // 16-bit float storage <-> fp32 math.

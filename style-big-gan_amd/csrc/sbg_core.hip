@@ -21,6 +21,7 @@ bool sbg_launch_geometry_ok(dim3 grid, dim3 block, size_t lds_bytes, const char*
     return ok;
 }
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -40,6 +41,16 @@ const char* sbg_env(const char* name)
 }
 
 extern "C" const char* sbg_last_error(void) { return sbg_err_slot().c_str(); }
+
+// Experiment word: kernel variants that are A/B-tested in ONE process (interleaved rounds on one device: scratch/kbench.py) select on its bits.
+// Initial value from SBG_EXPERIMENT; sbg_experiment_set returns the previous value.  Not part of the product's contract.
+static std::atomic<int>& sbg_experiment_word()
+{
+    static std::atomic<int> w{[] { const char* e = getenv("SBG_EXPERIMENT"); return e ? atoi(e) : 0; }()};
+    return w;
+}
+int sbg_experiment() { return sbg_experiment_word().load(std::memory_order_relaxed); }
+extern "C" int sbg_experiment_set(int v) { return sbg_experiment_word().exchange(v); }
 
 // ------------------------------------------------------------------------------------------------
 // Launch timing log.
