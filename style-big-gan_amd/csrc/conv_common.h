@@ -39,6 +39,7 @@ struct ConvArgs {
     int64_t ph_yoff[4];
     int ksplit;               // gather kernel: the K-steps are split over gridDim.y workgroups, each writing its own fp32 slab
     int64_t y_split_stride;   // elements between the slabs (0 when ksplit == 1)
+    int lds_params;   // halo kernel: a loader wave stages each tile's epilogue parameters (noise / bias / demodulation coefficients) in LDS
     int debug;        // ablation switches, honoured only by -DSBG_K64_DEBUG builds (diagnosis; see conv_k64.hip)
 };
 
@@ -47,6 +48,9 @@ struct ConvArgs {
 // conv_k64.hip: K-step-64 LDS-DMA kernels (gather and halo-staged).  Returns SBG_OK / an error, or -1 when the launch does not
 // fit these kernels (the caller then uses the kernels of conv_igemm.hip).
 int sbg_conv_k64_dispatch(sbgconv::ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, void* workspace, int ksplit, hipStream_t stream);
+// conv_halo8.hip: the 3x3 / stride-1 halo-staged tile in an 8-wave structure with two accumulator sets (a finished tile drains behind the next
+// one).  Returns SBG_OK / an error, or -1 when the launch stays with conv_k64.hip's conv_halo_ld_kernel.
+int sbg_conv_halo8_dispatch(sbgconv::ConvArgs& a, bool bf16, int64_t x_bytes, int64_t w_bytes, hipStream_t stream);
 // conv_thin.hip: few-channel convolutions (Cin, Cout <= 64, one of them <= 32) as a streaming kernel with the reduction axis packed
 // over (tap, channel).  Returns SBG_OK / an error, or -1 when the launch is not a thin one.
 int sbg_conv_thin_dispatch(sbgconv::ConvArgs& a, bool bf16, hipStream_t stream);

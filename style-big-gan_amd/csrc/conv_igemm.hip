@@ -434,7 +434,7 @@ extern "C" int sbg_conv2d_igemm(const sbg_conv_params* q, sbg_stream_t stream)
     a.stride = q->stride; a.ntaps = q->ntaps;
     for (int t = 0; t < SBG_MAX_TAPS; t++) { a.tap_dy[t] = q->tap_dy[t]; a.tap_dx[t] = q->tap_dx[t]; a.tap_slab[t] = q->tap_slab[t]; }
     a.accumulate = q->accumulate;
-    a.P = (int)P; a.ptiles = a.ctiles = 0; a.debug = sbg_experiment() << 8; a.ksplit = 1; a.y_split_stride = 0;
+    a.P = (int)P; a.ptiles = a.ctiles = 0; a.debug = sbg_experiment() << 8; a.lds_params = 0; a.ksplit = 1; a.y_split_stride = 0;
     a.nphase = 1; a.ph_rot_div = 1;
     for (int i = 0; i < 4; i++) { a.ph_tap0[i] = 0; a.ph_ntaps[i] = 0; a.ph_OH[i] = 0; a.ph_OW[i] = 0; a.ph_P[i] = 0; a.ph_yoff[i] = 0; }
     hipStream_t s = (hipStream_t)stream;

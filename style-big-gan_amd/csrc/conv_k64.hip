@@ -46,8 +46,16 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt_const() { asm
 // Straight-line fast path of the epilogue (layout of the accumulators: see conv_epilogue8 below): the output dtype and "no epilogue math" are template parameters, every 8-channel group of the
 // wave is in range and 16-B aligned (checked by the caller), so the loops below carry no per-element guards and no dtype
 // branches: leaky ReLU with alpha 0 / 1 covers ReLU / linear, clamp = med3 with an infinite bound when disabled.
-template <int TC, int TP, int YDT, bool PLAIN, bool NUNI, class PixFn>
-static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix, int64_t ybase)
+// `lp`: the tile's epilogue parameters staged in LDS by a loader wave (halo kernel: [noise of the TH x TW tile, row-major | bias of the 128 tile
+// channels | demodulation coefficients of (image, 128 tile channels)], 1 KiB each, fp32) -- the loads below then come from LDS (~100 cycles)
+// instead of L2 / HBM (a round trip of 1-2 us under load, paid by both compute groups at every tile boundary); lp_c = channel offset of this wave
+// inside the tile, lp_pix(j) = the pixel's index inside the tile.
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) const float4_t lds_cfloat4;
+struct LdsParams { lds_cfloat* base; int c; int tw; };
+template <int TC, int TP, int YDT, bool PLAIN, bool NUNI, bool LP = false, class PixFn>
+static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix, int64_t ybase,
+                                                          const LdsParams* lp = nullptr, int y0 = 0, int x0 = 0)
 {
     // NUNI: every pixel of the wave lies in one image (halo kernel), so the demodulation coefficients are per-h constants.
     // Every parameter load (noise per pixel, bias and demodulation coefficients per channel group) is issued up front and UNCONDITIONALLY -- an
@@ -69,7 +77,10 @@ static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, flo
         nn[j] = n;
         yoff[j] = ybase + (int64_t)blockIdx.y * p.y_split_stride + (int64_t)n * p.ys_n + (int64_t)oy * p.ys_h + (int64_t)ox * p.ys_w + cbase + 8 * fg;
         nz[j] = 0.f;
-        if (!PLAIN) nz[j] = *(has_nz ? p.noise + ((int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox) : dummy);
+        if (!PLAIN) {
+            if constexpr (LP) nz[j] = lp->base[(oy - y0) * lp->tw + (ox - x0)];
+            else              nz[j] = *(has_nz ? p.noise + ((int64_t)n * p.noise_sn + (int64_t)oy * p.OW + ox) : dummy);
+        }
     }
     float4_t b_lo[TH2], b_hi[TH2], s_lo[TH2], s_hi[TH2];
 #pragma unroll
@@ -77,11 +88,17 @@ static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, flo
         b_lo[h] = b_hi[h] = float4_t{0.f, 0.f, 0.f, 0.f};
         s_lo[h] = s_hi[h] = float4_t{1.f, 1.f, 1.f, 1.f};
         if (!PLAIN) {
+            if constexpr (LP) {
+                lds_cfloat* b = lp->base + 256 + lp->c + 32 * h + 8 * fg;
+                b_lo[h] = *(lds_cfloat4*)b; b_hi[h] = *(lds_cfloat4*)(b + 4);
+                if (NUNI) { s_lo[h] = *(lds_cfloat4*)(b + 256); s_hi[h] = *(lds_cfloat4*)(b + 260); }
+            } else {
             const float* b = has_b ? p.bias + cbase + 32 * h + 8 * fg : dummy;
             b_lo[h] = *reinterpret_cast<const float4_t*>(b); b_hi[h] = *reinterpret_cast<const float4_t*>(has_b ? b + 4 : dummy);
             if (NUNI) {
                 const float* sc = has_s ? p.oscale + (int64_t)nn[0] * p.Cout + cbase + 32 * h + 8 * fg : dummy;
                 s_lo[h] = *reinterpret_cast<const float4_t*>(sc); s_hi[h] = *reinterpret_cast<const float4_t*>(has_s ? sc + 4 : dummy);
+            }
             }
         }
     }
@@ -134,7 +151,8 @@ static __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& p, flo
 // Epilogue: lane (fr, fg) holds, for the pixel of fragment column fr in segment j, channels cbase + 32 h + 8 fg + e with
 // e = 0..3 in acc[2h][j] and e = 4..7 in acc[2h + 1][j].  pix(j, n, oy, ox) -> in range?
 template <int TC, int TP, bool NUNI = false, class PixFn>
-static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix, int64_t ybase = 0)
+static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_t (&acc)[TC][TP], int cbase, int fg, PixFn pix, int64_t ybase = 0,
+                                                      const LdsParams* lp = nullptr, int y0 = 0, int x0 = 0)
 {
     constexpr int TH2 = TC / 2;
     const bool plain = (p.act <= SBG_ACT_LINEAR) && p.gain == 1.f && p.clamp < 0.f && !p.bias && !p.noise && !p.oscale;
@@ -144,9 +162,11 @@ static __device__ __forceinline__ void conv_epilogue8(const ConvArgs& p, float4_
     if (fast) {
         if (p.ydtype == SBG_BF16) {
             if (plain) conv_epilogue_fast<TC, TP, SBG_BF16, true, NUNI>(p, acc, cbase, fg, pix, ybase);
+            else if (lp) conv_epilogue_fast<TC, TP, SBG_BF16, false, NUNI, true>(p, acc, cbase, fg, pix, ybase, lp, y0, x0);
             else       conv_epilogue_fast<TC, TP, SBG_BF16, false, NUNI>(p, acc, cbase, fg, pix, ybase);
         } else {
             if (plain) conv_epilogue_fast<TC, TP, SBG_F32, true, NUNI>(p, acc, cbase, fg, pix, ybase);
+            else if (lp) conv_epilogue_fast<TC, TP, SBG_F32, false, NUNI, true>(p, acc, cbase, fg, pix, ybase, lp, y0, x0);
             else       conv_epilogue_fast<TC, TP, SBG_F32, false, NUNI>(p, acc, cbase, fg, pix, ybase);
         }
         return;
@@ -408,6 +428,8 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const sH = smem + NSTAGE * STAGE;
+    unsigned char* const sP = sH + 2 * HALO_BYTES;     // epilogue parameters of the tile being computed: two buffers (tile parity) of 3 KiB
+    constexpr int PARAM_BYTES = 3072;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -430,6 +452,17 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         r.c0 = ct_ * BC; r.tn = pt_ / tiles_y; r.y0 = ty * TH; r.x0 = tx * TW;
         return r;
     };
+    // tile + G without divisions: G in the mixed radix (ctiles, tiles_x, tiles_y), added with carries.  (decode()'s four scalar divisions are
+    // ~1000 cycles; the compute waves ran them between a tile's last MFMA and the barrier their partner group was waiting at.)
+    const TileC gstep = decode(G);                       // digits of G, scaled like the coordinates
+    auto advance = [&](TileC t_) -> TileC {
+        t_.c0 += gstep.c0; int carry = t_.c0 >= p.ctiles * BC; t_.c0 -= carry ? p.ctiles * BC : 0;
+        t_.x0 += gstep.x0 + (carry ? TW : 0); carry = t_.x0 >= tiles_x * TW; t_.x0 -= carry ? tiles_x * TW : 0;
+        t_.y0 += gstep.y0 + (carry ? TH : 0); carry = t_.y0 >= tiles_y * TH; t_.y0 -= carry ? tiles_y * TH : 0;
+        t_.tn += gstep.tn + carry;
+        return t_;
+    };
+    const bool inc = !((p.debug >> 8) & 64);             // experiment bit 64: decode() at every tile
     const int lrow = lane >> 3;
     const int src_k = ((lane & 7) ^ lrow) * 8;          // DMA lane -> (row = 8 piece + lrow, slot = lane & 7), source k-slot = slot ^ (row & 7)
 
@@ -453,6 +486,31 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(sH + buf * HALO_BYTES + piece * 1024), 16, off, 0, 0, 0);
             }
         };
+        // epilogue parameters of tile `t_` -> parameter buffer `buf` (wave 10 only): the noise of the TH x TW tile (one 16-B piece per lane, row-major),
+        // the bias of the tile's 128 channels and the demodulation coefficients of (image, those channels) (lanes 0-31).  Issued during the tile's LAST
+        // slice; this wave's vmcnt(0) in front of the next slice's first barrier covers them, and the tile's epilogue runs behind that barrier.
+        auto issue_params = [&](int t_, int buf) {
+            const TileC pc = decode(t_);
+            unsigned char* dst = sP + buf * PARAM_BYTES;
+            if (p.noise) {
+                __amdgpu_buffer_rsrc_t nr = __builtin_amdgcn_make_buffer_rsrc((void*)p.noise, 0, 0x7fffffff, 0x00020000);
+                constexpr int LPR = TW / 4;
+                const int r = lane / LPR, cx = (lane - r * LPR) * 4;
+                const unsigned off = (unsigned)(pc.tn * (int)p.noise_sn + (pc.y0 + r) * p.OW + pc.x0 + cx) * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(nr, (lds_void_ptr)dst, 16, off, 0, 0, 0);
+            }
+            const int co = pc.c0 + 4 * lane;
+            const unsigned okm = 0u - (unsigned)((lane < 32) & (co < p.Cout));
+            if (p.bias) {
+                __amdgpu_buffer_rsrc_t br_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, 0x7fffffff, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(br_, (lds_void_ptr)(dst + 1024), 16, (((unsigned)co * 4u) & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
+            }
+            if (p.oscale) {
+                __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)p.oscale, 0, 0x7fffffff, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (lds_void_ptr)(dst + 2048), 16, (((unsigned)(pc.tn * p.Cout + co) * 4u) & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
+            }
+        };
+        int ctile = bid, cchunk = 0, cpar = 0;          // tile / chunk of the slice being computed, parity of that tile's ordinal
         int tile = bid, chunk = 0;
         TileC tc = decode(tile);
         issue_halo(tc, 0, 0, 0, HPL);
@@ -475,8 +533,11 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
 #pragma unroll
             for (int i = 0; i < 17; i++) {
                 if (spread && more && per * i < HPL) issue_halo(tc, chunk, (c + 1) & 1, per * i, per * i + per < HPL ? per * i + per : HPL);
+                if (i == 12 && lh == 0 && p.lds_params && cchunk == kchunks - 1) issue_params(ctile, cpar);
+                if (i == 16 && p.lds_params && c + 1 == nslices) wait_vmcnt_const<0>();      // the LAST tile's parameters have no later slice whose first barrier would cover them
                 __builtin_amdgcn_s_barrier();
             }
+            if (++cchunk == kchunks) { cchunk = 0; ctile += G; cpar ^= 1; }
         }
         __builtin_amdgcn_s_barrier();                    // 2S
         return;
@@ -570,13 +631,15 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
     // short-K tile: 18 K-steps at Cin = 128).
     bool pend = false;
     TileC done = cur;
+    int tpar = 0, done_par = 0;                          // parity of the current / finished tile's ordinal: its parameter buffer
     auto epilogue = [&](const TileC& tc) __attribute__((always_inline)) {
+        const LdsParams lp{(lds_cfloat*)(sP + done_par * PARAM_BYTES), wc, TW};
         if (!(dbg & 8))
         conv_epilogue8<TC, TP, true>(p, acc, tc.c0 + wc, fg, [&](int j, int& n, int& oy, int& ox) {
             const int sg = wpi * TP + j, r = sg / SEG, cseg = (sg - r * SEG) * 16;
             n = tc.tn; oy = tc.y0 + r; ox = tc.x0 + cseg + fr;
             return true;
-        });
+        }, 0, p.lds_params ? &lp : nullptr, tc.y0, tc.x0);
 #pragma unroll
         for (int i = 0; i < TC; i++)
 #pragma unroll
@@ -619,9 +682,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         });
         par ^= 1;
         if (++chunk < kchunks) continue;
-        pend = true; done = cur;
+        pend = true; done = cur; done_par = tpar; tpar ^= 1;
         chunk = 0; tile += G;
-        if (tile < ntiles) cur = decode(tile);
+        if (tile < ntiles) cur = inc ? advance(cur) : decode(tile);
     }
     if (pend) epilogue(done);
     if (!grpY) __builtin_amdgcn_s_barrier();             // 2S
@@ -861,7 +924,15 @@ template <class MF, int TH, int TW>
 static int launch_halo_ld(ConvArgs& a, unsigned x_bytes, unsigned w_bytes, hipStream_t stream)
 {
     constexpr int HPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
-    constexpr int lds = 4 * 128 * 128 + 2 * HPIECES * 1024;
+    constexpr int lds = 4 * 128 * 128 + 2 * HPIECES * 1024 + 2 * 3072;
+    {   // the epilogue parameters go through LDS when the epilogue's 16-B fast path applies and the noise rows are 16-B aligned
+        const bool plain = (a.act <= SBG_ACT_LINEAR) && a.gain == 1.f && a.clamp < 0.f && !a.bias && !a.noise && !a.oscale;
+        const bool fast = ((a.Cout & 7) == 0) && ((((uintptr_t)a.y) & 15) == 0) && (((a.ys_n | a.ys_h | a.ys_w) & 7) == 0)
+                          && ((((uintptr_t)a.oscale) & 15) == 0) && ((((uintptr_t)a.bias) & 15) == 0) && a.ydtype != SBG_F16;
+        const bool nz_ok = !a.noise || (((((uintptr_t)a.noise) & 15) == 0) && (a.noise_sn & 3) == 0 && (a.OW & 3) == 0
+                                        && (int64_t)a.N * (a.noise_sn > 0 ? a.noise_sn : 0) + (int64_t)a.OH * a.OW < (1ll << 28));
+        a.lds_params = !plain && fast && nz_ok && (int64_t)a.N * a.Cout < (1ll << 28) && !((a.debug >> 8) & 32);      // experiment bit 32: parameters from global memory
+    }
     static_assert(lds <= 160 * 1024, "LDS budget");
     a.ctiles = (a.Cout + 127) / 128;
     a.ptiles = a.N * (a.OH / TH) * (a.OW / TW);
@@ -965,6 +1036,8 @@ static int dispatch_k64(ConvArgs& a, int level, unsigned xb, unsigned wb, hipStr
     for (int t = 0; halo && t < 9; t++) halo = a.tap_dy[t] >= -1 && a.tap_dy[t] <= 1 && a.tap_dx[t] >= -1 && a.tap_dx[t] <= 1;
     const int64_t tiles256 = (int64_t)((a.P + 255) / 256) * ((a.Cout + 127) / 128);
     if (halo && a.Cout > 64 && tiles256 >= 256) {
+        const int rc8 = sbg_conv_halo8_dispatch(a, std::is_same<MF, bf16_mfma>::value, xb, wb, stream);
+        if (rc8 != -1) return rc8;
         if (a.OW % 32 == 0 && a.OH % 8 == 0)  return launch_halo_ld<MF, 8, 32>(a, xb, wb, stream);
         if (a.OW % 16 == 0 && a.OH % 16 == 0) return launch_halo_ld<MF, 16, 16>(a, xb, wb, stream);
     }

@@ -55,6 +55,7 @@ int sbg_experiment();                       // experiment word (SBG_EXPERIMENT /
 typedef __attribute__((ext_vector_type(8))) short  short8_t;
 typedef __attribute__((ext_vector_type(4))) short  short4_t;
 typedef __attribute__((ext_vector_type(4))) float  float4_t;
+typedef __attribute__((ext_vector_type(4))) int    int4_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 

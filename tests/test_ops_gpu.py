@@ -279,6 +279,37 @@ def test_thin_channel_kernels_multi_tile(dev, dtype):
     assert len(thin_wgrad) >= 5, [r["dims"] for r in rec if r["kind"] == "conv_wgrad"]
 
 
+def test_conv_halo8_experimental_kernel(dev):
+    """csrc/conv_halo8.hip (8 waves, a finished tile drains behind the next one; opt-in through the experiment word, bit 256 -- DESIGN.md section 4
+    says why it is not the default): same launches, same results as the 12-wave halo kernel -- plain and with the fused tail, 8 x 32 and 16 x 16
+    tiles, one and several tiles per workgroup, one and several channel tiles; the launch log must show code 5xxxxxx."""
+    from style_big_gan_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(12)
+    cases = [(4, 64, 128, 64, 128), (36, 64, 128, 48, 48), (3, 128, 256, 160, 160), (2, 192, 128, 128, 256)]      # n, cin, cout, h, w
+    for n, cin, cout, h, w in cases:
+        xq = torch.randn(n, cin, h, w).to(torch.bfloat16).float(); wq = (torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)).to(torch.bfloat16).float()
+        osc = torch.rand(n, cout) + 0.5; noise = torch.randn(n, 1, h, w); bias = torch.randn(cout)
+        conv = torch.nn.functional.conv2d(xq, wq, padding=1)
+        ref_tail = O.bias_act(conv * osc[:, :, None, None] + noise, bias, act="lrelu", gain=1.2, clamp=1.5)
+        epi = conv2d_gradfix.Epilogue(oscale=osc.to(dev), noise=noise.to(dev), bias=bias.to(dev), act="lrelu", alpha=0.2, gain=1.2, clamp=1.5)
+        xg = xq.to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last); wg = wq.to(dev, torch.bfloat16)
+        base_plain = conv2d_gradfix._conv_forward(xg, wg, (1, 1), (1, 1))
+        base_tail = conv2d_gradfix._conv_forward(xg, wg, (1, 1), (1, 1), epi=epi)
+        lib.sbg_experiment_set(256)
+        try:
+            _lib.prof_enable(True); _lib.prof_fetch()
+            got_plain = conv2d_gradfix._conv_forward(xg, wg, (1, 1), (1, 1))
+            got_tail = conv2d_gradfix._conv_forward(xg, wg, (1, 1), (1, 1), epi=epi)
+            _lib.prof_enable(False)
+            codes = [r["dims"][6] // 1000000 for r in _lib.prof_fetch() if r["kind"] == "conv_igemm"]
+        finally:
+            lib.sbg_experiment_set(0)
+        assert codes == [5, 5], (codes, n, cin, cout, h, w)
+        check(got_plain, conv, 2e-2, "halo8 plain vs oracle"); check(got_tail, ref_tail, 2e-2, "halo8 tail vs oracle")
+        assert torch.equal(got_plain, base_plain) and torch.equal(got_tail, base_tail), "halo8 differs from the 12-wave kernel"
+
+
 def test_split_bf16_cat_dense_of_strided_view(dev):
     """sbg_split_bf16_cat_nd on a permuted weight view == the memory-order split followed by .contiguous(), bit for bit; the parts sum back
     to the fp32 value within 2^-24 relative"""
