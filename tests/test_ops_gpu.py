@@ -286,7 +286,7 @@ def test_conv_halo8_experimental_kernel(dev):
     from style_big_gan_amd import _lib
     lib = _lib.load()
     torch.manual_seed(12)
-    cases = [(4, 64, 128, 64, 128), (36, 64, 128, 48, 48), (3, 128, 256, 160, 160), (2, 192, 128, 128, 256)]      # n, cin, cout, h, w
+    cases = [(8, 64, 128, 64, 128), (36, 64, 128, 48, 48), (3, 128, 256, 160, 160), (2, 192, 128, 128, 256)]      # n, cin, cout, h, w
     for n, cin, cout, h, w in cases:
         xq = torch.randn(n, cin, h, w).to(torch.bfloat16).float(); wq = (torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)).to(torch.bfloat16).float()
         osc = torch.rand(n, cout) + 0.5; noise = torch.randn(n, 1, h, w); bias = torch.randn(cout)
