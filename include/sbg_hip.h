@@ -197,6 +197,11 @@ int sbg_scale_shift_nc(const void* x, const float* a, const float* b, void* y, i
 int sbg_dot_hw_splits(int layout, int N, int C, int64_t HW);
 int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layout,
                int N, int C, int64_t HW, sbg_stream_t stream);
+/* r[0][n*C + c] = sum over the H*W plane of x, r[1][n*C + c] = sum of x^2 -- both moments of a PLANAR tensor [N, C, H*W] in one pass (fp32
+ * accumulation, fixed order).  The batch statistics of BigGAN's normalisation layers (biggan/layers.py:188-205 `manual_bn`,
+ * sync_batchnorm/batchnorm.py:71-79: `input_sum`, `input_ssum`).  r: fp32 [2, N*C]. */
+int sbg_moments_hw(const void* x, float* r, int dtype, int N, int C, int64_t HW, sbg_stream_t stream);
+
 /* Both gradients of y = x * a[n, c] (the style modulation in front of a convolution, train_parts/generators.py:79; autograd's
  * `dy * a` and `(dy * x).sum([2, 3])`) in ONE pass over u = dy and v = x, channel-minor tensors with C / 8 dividing 256:
  *   y[n,p,c] = u[n,p,c] * scale[n*C + c]     and     partial[s][n*C + c] as sbg_dot_hw(u, v). */

@@ -13,7 +13,7 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 # --single-thread-autograd: every kernel is submitted by ONE host thread (one of the hypotheses tested for the counter-collection aborts
 # below; it did not remove them, and is kept so that launch order = dispatch order for the launch-log join of summarize.py).
-CMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --single-thread-autograd"
+CMD="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --single-thread-autograd"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG --output-format csv -- $CMD --launch-log $OUT/launch_log.jsonl > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 echo "stats pass done"
 # Counter-collection passes.  rocprofv3 counter collection on this pool dies now and then in the first seconds of a run -- queue abort

@@ -14,7 +14,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 out, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-FAMILIES = ('conv_thin_kernel', 'conv_up2_kernel', 'upfirdn2d_fir_slide_kernel', 'conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_ksplit_reduce', 'upfirdn2d_fir_mfma_kernel',
+FAMILIES = ('conv_thin_kernel', 'conv_up2_kernel', 'conv_halo8_kernel', 'upfirdn2d_fir_slide_kernel', 'conv_halo_ld_kernel', 'conv_gather_ld_kernel', 'conv_k64_kernel', 'conv_ksplit_reduce', 'upfirdn2d_fir_mfma_kernel',
             'upfirdn2d_fir_fixed_kernel', 'modconv_bwd_kernel', 'conv_igemm_dma_kernel', 'conv_igemm_kernel', 'conv_wgrad_rows_kernel', 'conv_wgrad_halo_kernel',
             'conv_wgrad_kernel', 'wgrad_reduce_kernel', 'upfirdn2d_fir_kernel', 'upfirdn2d_kernel', 'attention_bwd', 'attention_fwd', 'mbstd', 'bias_act', 'scale_nc', 'dot_hw')
 
@@ -44,9 +44,11 @@ def log_family(rec):
             return 'conv_thin_kernel'
         if top == 9:
             return 'conv_up2_kernel'
+        if top == 5:
+            return 'conv_halo8_kernel'
         return 'conv_gather_ld_kernel' if top >= 4 else None
     if rec['kind'] == 'conv_wgrad':
-        return 'conv_wgrad_rows_kernel' if code >= 1000000 else None      # the generic weight-gradient kernel launches once per tap group: not joined
+        return 'conv_wgrad_rows_kernel' if code // 1000000 == 1 else None      # (3xxxxxx: the thin kernel; the generic weight-gradient kernel launches once per tap group: not joined)
     return None
 
 

@@ -130,6 +130,7 @@ SYMBOLS = [
     ("sbg_attention_bwd", _c.c_int, [_c.c_void_p] * 8 + [_c.c_int] * 5 + [_c.c_void_p]),
     ("sbg_dot_hw_splits", _c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64]),
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
+    ("sbg_moments_hw", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_dot_hw_scale_supported", _c.c_int, [_c.c_int]),
     ("sbg_dot_hw_scale", _c.c_int, [_c.c_void_p] * 5 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_modconv_bwd_supported", _c.c_int, [_c.c_int]),

@@ -245,8 +245,8 @@ def batch_stats(x, cross_replica=False):
     """per-channel (mean, biased var, unbiased var, count) over (N, H, W) [and over ranks]; fp32, differentiable"""
     n, c, h, w = x.shape
     if x.device.type == "cuda":
-        s1 = modulate.dot_hw(x).sum(0)
-        s2 = modulate.dot_hw(x, x).sum(0)
+        m1, m2 = modulate.moments_hw(x)      # one pass over x for both moments (sbg_moments_hw)
+        s1, s2 = m1.sum(0), m2.sum(0)
     else:   # plumbing path for CPU-only unit tests of the host logic
         xf = x.float()
         s1, s2 = xf.sum([0, 2, 3]), xf.square().sum([0, 2, 3])
@@ -273,7 +273,7 @@ def normalize(x, mean, var, gain, bias, eps):
 def _moments_nc(x):
     """per-sample, per-channel (sum x, sum x^2) over (H, W) in fp32: [N, C] each, differentiable"""
     if x.device.type == "cuda":
-        return modulate.dot_hw(x), modulate.dot_hw(x, x)
+        return modulate.moments_hw(x)
     xf = x.float()
     return xf.sum([2, 3]), xf.square().sum([2, 3])
 

@@ -462,7 +462,6 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         t_.tn += gstep.tn + carry;
         return t_;
     };
-    const bool inc = !((p.debug >> 8) & 64);             // experiment bit 64: decode() at every tile
     const int lrow = lane >> 3;
     const int src_k = ((lane & 7) ^ lrow) * 8;          // DMA lane -> (row = 8 piece + lrow, slot = lane & 7), source k-slot = slot ^ (row & 7)
 
@@ -519,8 +518,8 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         // meets at the next barrier, and a burst of 22 made that one half-step ~4x as long as the 32 MFMAs it should hide behind.  Measured
         // (scratch/kbench_ab.py, interleaved rounds on one device, [64, C, R, R] (*) [C, C, 3, 3]): C = 128 @ 256^2 1070 -> 1160 TF,
         // 256 @ 128^2 1154 -> 1300, 512 @ 64^2 1214 -> 1389, 512 @ 32^2 1273 -> 1390; three or four per half-step 1090-1110 / 1220-1250 /
-        // 1280-1310.  Experiment bit 2 restores the burst.
-        const bool spread = !((p.debug >> 8) & 2);
+        // 1280-1310.
+        constexpr bool spread = true;
         const int per = 2;                               // pieces per half-step
         for (int c = 0; c < nslices; c++) {
             wait_vmcnt_const<0>();                       // halo(c) has landed
@@ -528,7 +527,6 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             const bool more = c + 1 < nslices && !(dbg & 2) && !(dbg & 32);       // 32: halo loads only
             if (more) {
                 if (++chunk == kchunks) { chunk = 0; tile += G; tc = decode(tile); }
-                if (!spread) issue_halo(tc, chunk, (c + 1) & 1, 0, HPL);
             }
 #pragma unroll
             for (int i = 0; i < 17; i++) {
@@ -582,7 +580,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             }
         };
         auto issue_next = [&]() { issue_prep(); issue_part(0, WPIECES); issue_done(); };
-        const bool split = (p.debug >> 8) & 1;           // experiment (off): half of a step's pieces behind each of its two barriers -- +2..4 % alone, -1 % beside the spread halo loads
+        constexpr bool split = false;                    // (half of a step's pieces behind each of its two barriers: +2..4 % alone, -1 % beside the spread halo loads)
         const int S = nslices * NT;
         int issued = 0;                                  // steps issued so far
         for (; issued < 4 && issued < S; issued++) issue_next();
@@ -684,7 +682,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         if (++chunk < kchunks) continue;
         pend = true; done = cur; done_par = tpar; tpar ^= 1;
         chunk = 0; tile += G;
-        if (tile < ntiles) cur = inc ? advance(cur) : decode(tile);
+        if (tile < ntiles) cur = advance(cur);
     }
     if (pend) epilogue(done);
     if (!grpY) __builtin_amdgcn_s_barrier();             // 2S
@@ -803,7 +801,7 @@ __global__ __launch_bounds__(768, 3) void conv_gather_ld_kernel(ConvArgs p, unsi
             }
         };
         auto issue_next = [&]() { issue_part(-1); issue_done(); };
-        const bool split = !((p.debug >> 8) & 4);        // half of a step's pieces behind each of its two barriers (+0.5..1 %; experiment bit 4: all behind the first)
+        constexpr bool split = true;                     // half of a step's pieces behind each of its two barriers (+0.5..1 %)
         int issued = 0;                                  // steps issued so far
         for (; issued < NSTAGE && issued < S; issued++) issue_next();
         for (int s = 0; s < S; s++) {

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(512) void conv_up2_kernel(ConvArgs p, unsigned x_by
     // `late`: a step's four DMA instructions go out one behind each group of eight MFMAs, not together in front of the step's first fragment
     // read: all eight waves leave the barrier together, so four back-to-back LDS-DMA issues (~100 cycles each) kept the matrix pipe idle at the
     // head of every step.  Measured (scratch/kbench_ab.py, one device, interleaved): [64,256,128^2] -> 128 725 -> 781 TF, [64,512,64^2] -> 256
-    // 841 -> 936, [64,512,32^2] -> 512 826 -> 918 (border launch included).  Experiment bit 8 restores the early issue.
-    const bool late = !((p.debug >> 8) & 8);
+    // 841 -> 936, [64,512,32^2] -> 512 826 -> 918 (border launch included).  
+    constexpr bool late = true;              // (the early form is in the history: as a run-time switch it cost nine spilled registers)
 
     // ---- prologue: halo of slice 0 (five slots per wave), weights of steps 0, 1, 2
 #pragma unroll
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512) void conv_up2_kernel(ConvArgs p, unsigned x_by
             };
             constexpr int k3 = (k + LEAD) % NSTEP;
             const int c3 = c + (k + LEAD) / NSTEP;
-            if (!late) {
+            if constexpr (!late) {
                 if constexpr (k < 3) { dma_halo_piece(0); dma_halo_piece(1); }
                 dma_w(c3, k3, (slot + LEAD) & (NRING - 1), c3 < kchunks);
             }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512) void conv_up2_kernel(ConvArgs p, unsigned x_by
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) acc[ph][i][j] = Mfma<MF>::run(fa[buf][i], fb[buf][j], acc[ph][i][j]);
-                if (late) {
+                if constexpr (late) {
                     // group g of NG carries DMA instructions [g * 4 / NG, (g + 1) * 4 / NG) of the step's four: weight piece 0, 1, halo piece 0, 1
                     constexpr int d0 = g * 4 / NG, d1 = (g + 1) * 4 / NG;
                     sbg_static_for<4>([&](auto dt) {

@@ -323,8 +323,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_rows_kernel(WgradArgs p, unsig
     // `late`: the DMA instructions of chunk s + DEPTH go out spread over the tap loop, each behind a tap's MFMAs, instead of together right
     // behind the barrier (where all eight waves issued them at once and the matrix pipe waited).  Measured (scratch/kbench_ab.py, one device,
     // interleaved rounds, 64 images): 128 x 128 @ 256^2 1060 -> 1135 TF, 256 x 256 @ 128^2 1149 -> 1227, 512 x 512 @ 64^2 1204 -> 1285,
-    // stride 2: 256 x 128 917 -> 1016, 512 x 256 966 -> 1081.  Experiment bit 16 restores the early issue.
-    const bool late = !(p.experiment & 16);
+    // stride 2: 256 x 128 917 -> 1016, 512 x 256 966 -> 1081.  
+    constexpr bool late = true;
 
     const int wa = (wave >> 2) * (BCA / 2), wb = (wave & 3) * 16;
     const int fi = lane & 15, fg = lane >> 4, fq = fi >> 2, fp = fi & 3;

@@ -353,6 +353,51 @@ extern "C" int sbg_dot_hw(const void* u, const void* v, float* partial, int dtyp
 }
 
 
+// ---- moments_hw: r[0][n,c] = sum_p x, r[1][n,c] = sum_p x^2 in ONE pass over a planar tensor (the batch statistics of BigGAN's normalisation
+// layers: reference biggan/layers.py:188-205 `manual_bn`, sync_batchnorm/batchnorm.py:71-79 -- two reductions over x there, two dot_hw launches
+// here until round 3).  One workgroup per (n, c) plane, 16-B loads when the plane allows, fp32 accumulation, fixed-order tree.
+template <class T>
+__global__ __launch_bounds__(256) void moments_hw_planar(const T* x, float* r, int64_t NC, int64_t HW, int vec)
+{
+    __shared__ float red[2][256];
+    const int64_t nc = blockIdx.x;
+    const T* px = x + nc * HW;
+    float s1 = 0.f, s2 = 0.f;
+    if (vec) {
+        const int64_t nv = HW >> 3;
+        for (int64_t i = threadIdx.x; i < nv; i += 256) {
+            float v[8];
+            Vec8<T>::ld(px + i * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { s1 += v[e]; s2 += v[e] * v[e]; }
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < HW; i += 256) { const float a = Elem<T>::ld(px + i); s1 += a; s2 += a * a; }
+    }
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if ((int)threadIdx.x < stride) { red[0][threadIdx.x] += red[0][threadIdx.x + stride]; red[1][threadIdx.x] += red[1][threadIdx.x + stride]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { r[nc] = red[0][0]; r[NC + nc] = red[1][0]; }
+}
+
+extern "C" int sbg_moments_hw(const void* x, float* r, int dtype, int N, int C, int64_t HW, sbg_stream_t stream)
+{
+    SBG_CHECK(x && r, "moments_hw: null pointer");
+    SBG_CHECK(dtype == SBG_F32 || dtype == SBG_F16 || dtype == SBG_BF16, "moments_hw: unsupported dtype %d", dtype);
+    SBG_CHECK(N >= 1 && C >= 1 && HW >= 1 && (int64_t)N * C <= INT32_MAX, "moments_hw: bad sizes");
+    const int64_t NC = (int64_t)N * C;
+    const int vec = sbg_aligned16(x) && (HW % 8) == 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SBG_F32)      SBG_LAUNCH((moments_hw_planar<float>), dim3((unsigned)NC), dim3(256), 0, s, (const float*)x, r, NC, HW, vec);
+    else if (dtype == SBG_F16) SBG_LAUNCH((moments_hw_planar<f16_s>), dim3((unsigned)NC), dim3(256), 0, s, (const f16_s*)x, r, NC, HW, vec);
+    else                       SBG_LAUNCH((moments_hw_planar<bf16_s>), dim3((unsigned)NC), dim3(256), 0, s, (const bf16_s*)x, r, NC, HW, vec);
+    SBG_HIP_LAUNCH_CHECK();
+    return SBG_OK;
+}
+
 // One pass over (u, v) for both gradients of y = x * a[n, c] given u = dy, v = x:  partial sums of u * v (-> da) AND dx = u * scale.
 extern "C" int sbg_dot_hw_scale_supported(int C)
 {

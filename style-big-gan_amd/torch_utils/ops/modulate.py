@@ -124,6 +124,35 @@ class _DotHW(torch.autograd.Function):
         return du, dv
 
 
+class _MomentsHW(torch.autograd.Function):
+    """(sum x, sum x^2) over (H, W) of a planar tensor in one pass: fp32 [N, C] each.  d/dx = ds1[n, c] + 2 x ds2[n, c] (a scale_shift_nc pass,
+    itself differentiable)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        _lib.require_cuda(x, "moments_hw")
+        n, c, h, w = x.shape
+        r = torch.empty([2, n, c], dtype=torch.float32, device=x.device)
+        _lib.check(lib.sbg_moments_hw(_lib.ptr(x), _lib.ptr(r), _lib.dtype_code(x.dtype), n, c, h * w, _lib.stream_ptr(x.device)), "sbg_moments_hw")
+        ctx.save_for_backward(x)
+        return r[0], r[1]
+
+    @staticmethod
+    def backward(ctx, ds1, ds2):
+        (x,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None
+        return _ScaleShiftNC.apply(x, 2.0 * ds2, ds1)
+
+
+def moments_hw(x):
+    """x: [N, C, H, W] -> (x.sum([2, 3]), x.square().sum([2, 3])) in fp32; one pass for planar (contiguous NCHW) tensors, two dot_hw passes otherwise"""
+    if x.is_contiguous() and x.numel() > 0:
+        return _MomentsHW.apply(x)
+    return dot_hw(x), dot_hw(x, x)
+
+
 class _ScaleShiftNC(torch.autograd.Function):
     """y = x * a[n, c] + b[n, c];  a, b: fp32 [N, C]  (normalise-and-modulate step of the batch-norm layers)"""
 
