@@ -46,6 +46,10 @@ for job, vs in jobs.items():
             epi = cg.Epilogue(oscale=torch.rand(n, cout, device=dev) + 0.5, noise=torch.randn(n, 1, r, r, device=dev), bias=torch.randn(cout, device=dev),
                               act='lrelu', alpha=0.2, gain=1.4, clamp=256.0)
             ab(f'halo conv3x3 + tail {n}x{cin}->{cout}@{r}', lambda: cg._conv_forward(x, w, (1, 1), (1, 1), epi=epi), variants, 'conv_igemm')
+    if job == 'k64':           # stride-2 forward convolutions (the discriminator's conv1 layers / the data gradient of G's up-convolutions): 8-wave gather kernel
+        for (n, cin, cout, r) in [(64, 128, 256, 257), (64, 256, 512, 129), (64, 512, 512, 65)]:
+            x = cl(torch.randn(n, cin, r, r, device=dev, dtype=torch.bfloat16)); w = (torch.randn(cout, cin, 3, 3, device=dev) / 30).to(torch.bfloat16)
+            ab(f'conv3x3 s2 {n}x{cin}->{cout}@{r}', lambda: cg._conv_forward(x, w, (2, 2), (0, 0)), variants, 'conv_igemm')
     if job == 'up2':
         for (n, cin, cout, r) in [(64, 256, 128, 128), (64, 512, 256, 64), (64, 512, 512, 32)]:
             x = cl(torch.randn(n, cin, r, r, device=dev, dtype=torch.bfloat16)); w = (torch.randn(cin, cout, 3, 3, device=dev) / 30).to(torch.bfloat16)

@@ -430,6 +430,16 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
     unsigned char* const sH = smem + NSTAGE * STAGE;
     unsigned char* const sP = sH + 2 * HALO_BYTES;     // epilogue parameters of the tile being computed: two buffers (tile parity) of 3 KiB
     constexpr int PARAM_BYTES = 3072;
+#ifdef SBG_K64_STAMPS    // diagnosis build (scratch/halo_stamps.py): lane 0 of waves 0, 4, 8, 10 of workgroup 0 writes its clock in front of and behind every
+                         // barrier into the head of y (4096 records per wave pair); the outputs of that launch are garbage
+    unsigned long long* const stamp_base = (unsigned long long*)p.y + (threadIdx.x >> 7) * 4096;
+    const bool stamp_on = blockIdx.x == 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 4 || (threadIdx.x >> 6) == 8 || (threadIdx.x >> 6) == 10);
+    int stamp_i = 0;
+#define SBG_BARRIER() do { if (stamp_on && stamp_i < 4000) stamp_base[stamp_i] = __builtin_amdgcn_s_memtime(); stamp_i++; __builtin_amdgcn_s_barrier(); \
+                           if (stamp_on && stamp_i < 4000) stamp_base[stamp_i] = __builtin_amdgcn_s_memtime(); stamp_i++; } while (0)
+#else
+#define SBG_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         const int per = 2;                               // pieces per half-step
         for (int c = 0; c < nslices; c++) {
             wait_vmcnt_const<0>();                       // halo(c) has landed
-            __builtin_amdgcn_s_barrier();                // 18c
+            SBG_BARRIER();                // 18c
             const bool more = c + 1 < nslices && !(dbg & 2) && !(dbg & 32);       // 32: halo loads only
             if (more) {
                 if (++chunk == kchunks) { chunk = 0; tile += G; tc = decode(tile); }
@@ -533,11 +543,11 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
                 if (spread && more && per * i < HPL) issue_halo(tc, chunk, (c + 1) & 1, per * i, per * i + per < HPL ? per * i + per : HPL);
                 if (i == 12 && lh == 0 && p.lds_params && cchunk == kchunks - 1) issue_params(ctile, cpar);
                 if (i == 16 && p.lds_params && c + 1 == nslices) wait_vmcnt_const<0>();      // the LAST tile's parameters have no later slice whose first barrier would cover them
-                __builtin_amdgcn_s_barrier();
+                SBG_BARRIER();
             }
             if (++cchunk == kchunks) { cchunk = 0; ctile += G; cpar ^= 1; }
         }
-        __builtin_amdgcn_s_barrier();                    // 2S
+        SBG_BARRIER();                    // 2S
         return;
     }
     if (wave >= 8) {
@@ -591,14 +601,14 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             else if (newer == 2) wait_vmcnt_const<2 * WPIECES>();
             else if (newer == 1) wait_vmcnt_const<1 * WPIECES>();
             else wait_vmcnt_const<0>();
-            __builtin_amdgcn_s_barrier();                // 2s
+            SBG_BARRIER();                // 2s
             const bool go = s >= 1 && issued < S && !(dbg & 2) && !(dbg & 16);      // step s + 3 -> the stage step s - 1 was read from (16: weight loads only)
             if (go) { issue_prep(); issue_part(0, split ? WPIECES / 2 : WPIECES); }
-            __builtin_amdgcn_s_barrier();                // 2s + 1
+            SBG_BARRIER();                // 2s + 1
             if (go) { if (split) issue_part(WPIECES / 2, WPIECES); issue_done(); issued++; }
             else if (s >= 1 && issued < S) issued++;
         }
-        __builtin_amdgcn_s_barrier();                    // 2S
+        SBG_BARRIER();                    // 2S
         return;
     }
 
@@ -643,14 +653,14 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
 #pragma unroll
             for (int j = 0; j < TP; j++) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
     };
-    if (grpY) __builtin_amdgcn_s_barrier();              // 0
+    if (grpY) SBG_BARRIER();              // 0
     for (int c = 0; c < nslices; c++) {
         const unsigned char* hb = sH + par * HALO_BYTES;
         static_for<NT>([&](auto tap_tag) {
             constexpr int t = decltype(tap_tag)::value;
             const int shift = __builtin_amdgcn_readlane(tbl_shift, t);
             const unsigned char* sa = smem + stage * STAGE + wc * 128;
-            __builtin_amdgcn_s_barrier();                // B_a: the stage and the halo buffer of this step have landed
+            SBG_BARRIER();                // B_a: the stage and the halo buffer of this step have landed
             if (t == 0 && pend) { epilogue(done); pend = false; }
             if (!(dbg & 4)) {
 #pragma unroll
@@ -666,7 +676,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): fragments are in registers, this wave no longer reads the stage
-            __builtin_amdgcn_s_barrier();                // B_b
+            SBG_BARRIER();                // B_b
             __builtin_amdgcn_sched_barrier(0);
             if (!(dbg & 1))
 #pragma unroll
@@ -685,10 +695,11 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         if (tile < ntiles) cur = advance(cur);
     }
     if (pend) epilogue(done);
-    if (!grpY) __builtin_amdgcn_s_barrier();             // 2S
+    if (!grpY) SBG_BARRIER();             // 2S
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+#undef SBG_BARRIER
 // Gather kernel with loader waves: the 128 x 256 tile of conv_k64_kernel in the persistent 12-wave structure of
 // conv_halo_ld_kernel.  Waves 8-9 stream the weight tile, waves 10-11 gather the 256 pixel rows of the tap (im2col on the
 // fly, out-of-image rows at an out-of-range offset); three 48 KB stages, the loads of step s + 2 are issued while step s
