@@ -479,22 +479,6 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         // ---------------------------------------------------------------- halo loader (waves 10, 11) ----------------------
         const int lh = wave - 10;
         __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)x_bytes, 0x00020000);
-        auto issue_halo = [&](const TileC& tc, int chunk, int buf, int lo, int hi) {
-            const unsigned okc = 0u - (unsigned)(chunk * 64 + src_k < p.Cin);
-            const unsigned img = (unsigned)(tc.tn * (int)p.xs_n + chunk * 64 + src_k) * 2u;
-#pragma unroll 2
-            for (int i = lo; i < hi; i++) {
-                const int piece = lh * HPL + i;
-                if (piece >= HPIECES) break;
-                const int pp = piece * 8 + lrow;
-                const int py = pp / PW, px = pp - py * PW;
-                const int iy = tc.y0 - 1 + py, ix = tc.x0 - 1 + px;
-                const unsigned okm = okc & (0u - (unsigned)((pp < NPIX) & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW)));
-                const unsigned real = img + (unsigned)(iy * (int)p.xs_h + ix * (int)p.xs_w) * 2u;
-                const unsigned off = (real & okm) | (SBG_OOB_OFFSET & ~okm);      // branch-free: a masked-off lane would leave stale LDS bytes
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(sH + buf * HALO_BYTES + piece * 1024), 16, off, 0, 0, 0);
-            }
-        };
         // epilogue parameters of tile `t_` -> parameter buffer `buf` (wave 10 only): the noise of the TH x TW tile (one 16-B piece per lane, row-major),
         // the bias of the tile's 128 channels and the demodulation coefficients of (image, those channels) (lanes 0-31).  Issued during the tile's LAST
         // slice; this wave's vmcnt(0) in front of the next slice's first barrier covers them, and the tile's epilogue runs behind that barrier.
@@ -519,32 +503,69 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (lds_void_ptr)(dst + 2048), 16, (((unsigned)(pc.tn * p.Cout + co) * 4u) & okm) | (SBG_OOB_OFFSET & ~okm), 0, 0, 0);
             }
         };
+        // The loader's HPL pieces of a slice with everything per-lane worked out ONCE: rel[i] = byte offset of piece i's halo pixel (py, px) and k-slot from the halo's
+        // origin, flag bits {py == 0, py == PH - 1, px == 0, px == PW - 1, no pixel} (5 per piece, 6 pieces per word).  Per slice the origin's byte offset
+        // and the tile's edge mask are scalars, so an issue is ~5 vector instructions instead of ~25 (a division by PW, two range tests, three multiplies).
+        // The loader waves share their SIMDs with the compute waves and were the last to arrive at every second barrier (scratch/halo_stamps.py):
+        // +3 .. 4.5 % (scratch/kbench_ab.py).
+        int rel[HPL]; unsigned ef[(HPL + 5) / 6];
+#pragma unroll
+        for (int w_ = 0; w_ < (HPL + 5) / 6; w_++) ef[w_] = 0;
+#pragma unroll
+        for (int i = 0; i < HPL; i++) {
+            const int piece = lh * HPL + i, pp = piece * 8 + lrow;
+            const int py = pp / PW, px = pp - py * PW;
+            rel[i] = (py * (int)p.xs_h + px * (int)p.xs_w + src_k) * 2;
+            const unsigned f = (unsigned)(py == 0) | ((unsigned)(py == PH - 1) << 1) | ((unsigned)(px == 0) << 2) | ((unsigned)(px == PW - 1) << 3)
+                             | ((unsigned)((piece >= HPIECES) | (pp >= NPIX)) << 4);
+            ef[i / 6] |= f << (5 * (i % 6));
+        }
+        auto issue_halo = [&](auto i_tag, int hbase, unsigned emask, bool kok, int buf) {
+            constexpr int i = decltype(i_tag)::value;
+            const int piece = lh * HPL + i;
+            if (piece >= HPIECES) return;                // (wave-uniform)
+            const bool bad = (((ef[i / 6] >> (5 * (i % 6))) & emask) != 0u) | !kok;
+            const unsigned off = bad ? SBG_OOB_OFFSET : (unsigned)(rel[i] + hbase);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(sH + buf * HALO_BYTES + piece * 1024), 16, off, 0, 0, 0);
+        };
+        auto halo_base = [&](const TileC& t_, int chunk_) { return (t_.tn * (int)p.xs_n + (t_.y0 - 1) * (int)p.xs_h + (t_.x0 - 1) * (int)p.xs_w + chunk_ * 64) * 2; };
+        auto edge_mask = [&](const TileC& t_) {
+            const unsigned m = (unsigned)(t_.y0 == 0) | ((unsigned)(t_.y0 + TH == p.IH) << 1) | ((unsigned)(t_.x0 == 0) << 2) | ((unsigned)(t_.x0 + TW == p.IW) << 3) | 16u;
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+        };
         int ctile = bid, cchunk = 0, cpar = 0;          // tile / chunk of the slice being computed, parity of that tile's ordinal
         int tile = bid, chunk = 0;
         TileC tc = decode(tile);
-        issue_halo(tc, 0, 0, 0, HPL);
+        {
+            const int hbase = halo_base(tc, 0); const unsigned emask = edge_mask(tc);
+            static_for<HPL>([&](auto it_) { issue_halo(it_, hbase, emask, src_k < p.Cin, 0); });
+        }
         // The 22 pieces of the next slice go out TWO per half-step (behind each of the slice's first eleven barriers), not as one burst behind
         // the first: an LDS-DMA instruction costs its wave ~100+ cycles beside the compute waves' fragment reads, every wave of the workgroup
         // meets at the next barrier, and a burst of 22 made that one half-step ~4x as long as the 32 MFMAs it should hide behind.  Measured
         // (scratch/kbench_ab.py, interleaved rounds on one device, [64, C, R, R] (*) [C, C, 3, 3]): C = 128 @ 256^2 1070 -> 1160 TF,
         // 256 @ 128^2 1154 -> 1300, 512 @ 64^2 1214 -> 1389, 512 @ 32^2 1273 -> 1390; three or four per half-step 1090-1110 / 1220-1250 /
-        // 1280-1310.
-        constexpr bool spread = true;
-        const int per = 2;                               // pieces per half-step
+        // 1280-1310.  (One piece behind each of the later barriers instead of two behind the first eleven: no difference.)
+        constexpr int per = 2;                           // pieces per half-step
         for (int c = 0; c < nslices; c++) {
             wait_vmcnt_const<0>();                       // halo(c) has landed
             SBG_BARRIER();                // 18c
             const bool more = c + 1 < nslices && !(dbg & 2) && !(dbg & 32);       // 32: halo loads only
             if (more) {
-                if (++chunk == kchunks) { chunk = 0; tile += G; tc = decode(tile); }
+                if (++chunk == kchunks) { chunk = 0; tile += G; tc = advance(tc); }
             }
-#pragma unroll
-            for (int i = 0; i < 17; i++) {
-                if (spread && more && per * i < HPL) issue_halo(tc, chunk, (c + 1) & 1, per * i, per * i + per < HPL ? per * i + per : HPL);
+            const int hbase = halo_base(tc, chunk); const unsigned emask = edge_mask(tc);
+            const bool kok = chunk * 64 + src_k < p.Cin;
+            static_for<17>([&](auto it_) {
+                constexpr int i = decltype(it_)::value;
+                if (more) {
+                    if constexpr (per * i < HPL)     issue_halo(std::integral_constant<int, (per * i < HPL ? per * i : 0)>{}, hbase, emask, kok, (c + 1) & 1);
+                    if constexpr (per * i + 1 < HPL) issue_halo(std::integral_constant<int, (per * i + 1 < HPL ? per * i + 1 : 0)>{}, hbase, emask, kok, (c + 1) & 1);
+                }
                 if (i == 12 && lh == 0 && p.lds_params && cchunk == kchunks - 1) issue_params(ctile, cpar);
                 if (i == 16 && p.lds_params && c + 1 == nslices) wait_vmcnt_const<0>();      // the LAST tile's parameters have no later slice whose first barrier would cover them
                 SBG_BARRIER();
-            }
+            });
             if (++cchunk == kchunks) { cchunk = 0; ctile += G; cpar ^= 1; }
         }
         SBG_BARRIER();                    // 2S
@@ -573,7 +594,18 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             kokm = 0u - (unsigned)(ichunk * 64 + src_k < p.Cin);
             wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, it) + ichunk * 128);
         };
+        // Whole 64-channel slabs (Cin % 64 == 0): the step's (tap, slab) offset is a scalar and rides in the instruction's scalar offset, so a piece
+        // is the DMA and nothing else (a_base[i] stays 0x80000000 for a row past Cout: out of range with or without the scalar part).  The six vector
+        // instructions per piece this removes (48 per step, in waves that share their SIMDs with the compute waves) were worth +7 .. 9 %:
+        // [64, C, R, R] (*) [C, C, 3, 3], interleaved rounds: C = 128 @ 256^2 1187 -> 1270 TF, 256 @ 128^2 1321 -> 1439, 512 @ 64^2 1401 -> 1526.
+        const bool whole_k = (p.Cin & 63) == 0;
         auto issue_part = [&](int lo, int hi) {
+            if (whole_k) {
+#pragma unroll
+                for (int i = 0; i < WPIECES; i++)
+                    if (i >= lo && i < hi) __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + i * 1024), 16, a_base[i], wtap, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < WPIECES; i++) {
                 if (i < lo || i >= hi) continue;
@@ -590,7 +622,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
             }
         };
         auto issue_next = [&]() { issue_prep(); issue_part(0, WPIECES); issue_done(); };
-        constexpr bool split = false;                    // (half of a step's pieces behind each of its two barriers: +2..4 % alone, -1 % beside the spread halo loads)
+        constexpr bool split = false;                    // (half of a step's pieces behind each of its two barriers: +2..4 % alone, none beside the spread halo loads)
         const int S = nslices * NT;
         int issued = 0;                                  // steps issued so far
         for (; issued < 4 && issued < S; issued++) issue_next();
