@@ -269,14 +269,15 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
     // weights of (tap t, slice chunk) -> stage `stage`
     auto issue_w = [&](int t, int chunk, int stage) {
         unsigned char* st = smem + stage * STAGE;
-        const bool kok = chunk * 64 + src_k < p.Cin;
-        const unsigned wtap = (unsigned)(__builtin_amdgcn_readlane(tbl_wtap, t) + chunk * 128);
+        // the step's (tap, slab) offset is a scalar and rides in the instruction's scalar offset: a piece is the DMA alone.  Only the last slab of a
+        // ragged Cin masks lanes (a masked-off lane reads out of range -> zeros; skipping it would leave stale bytes in LDS)
+        const int wtap = __builtin_amdgcn_readlane(tbl_wtap, t) + chunk * 128;
+        const bool ragged = chunk * 64 + 64 > p.Cin;          // (wave-uniform)
 #pragma unroll
         for (int i = 0; i < IA; i++) {
-            // branch-free select: a masked-off lane would leave stale bytes in LDS instead of zeros
-            const unsigned okm = 0u - (unsigned)(kok & (a_base[i] != SBG_OOB_OFFSET));
-            const unsigned off = ((a_base[i] + wtap) & okm) | (SBG_OOB_OFFSET & ~okm);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + (wave * IA + i) * 1024), 16, off, 0, 0, 0);
+            unsigned off = a_base[i];
+            if (ragged) off = (chunk * 64 + src_k < p.Cin) ? off : SBG_OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(st + (wave * IA + i) * 1024), 16, off, wtap, 0, 0);
         }
     };
 
@@ -330,17 +331,28 @@ __global__ __launch_bounds__(512, 2) void conv_k64_kernel(ConvArgs p, unsigned x
             b_ix0[i] = ox * p.stride;
             b_base[i] = (unsigned)(n * (int)p.xs_n + src_k) * 2u;
         }
+        // Steps are tap-major, so the gathered pixel of a lane (and whether it lies in the image) changes only once per kchunks steps: its byte offset
+        // is worked out when the tap changes (x_off[], ~12 vector instructions per piece) and the slab within the tap rides in the instruction's scalar
+        // offset.  These waves issue the MFMAs too; at Cin = 512 seven of eight steps now issue their four pixel pieces with no arithmetic at all.
+        unsigned x_off[IB]; int x_tap = -1;
         auto issue_x = [&](int t, int chunk, int stage) {          // gathered pixels of (tap t, slice chunk) -> stage
             unsigned char* st = smem + stage * STAGE + A_BYTES;
-            const bool kok = chunk * 64 + src_k < p.Cin;
-            const int dy = __builtin_amdgcn_readlane(tbl_dy, t), dx = __builtin_amdgcn_readlane(tbl_dx, t);
+            if (t != x_tap) {                                      // (wave-uniform)
+                x_tap = t;
+                const int dy = __builtin_amdgcn_readlane(tbl_dy, t), dx = __builtin_amdgcn_readlane(tbl_dx, t);
+#pragma unroll
+                for (int i = 0; i < IB; i++) {
+                    const int iy = b_iy0[i] + dy, ix = b_ix0[i] + dx;
+                    const bool ok = ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW);
+                    x_off[i] = ok ? b_base[i] + (unsigned)(iy * (int)p.xs_h + ix * (int)p.xs_w) * 2u : SBG_OOB_OFFSET;
+                }
+            }
+            const bool ragged = chunk * 64 + 64 > p.Cin;           // (wave-uniform)
 #pragma unroll
             for (int i = 0; i < IB; i++) {
-                const int iy = b_iy0[i] + dy, ix = b_ix0[i] + dx;
-                const unsigned okm = 0u - (unsigned)(kok & ((unsigned)iy < (unsigned)p.IH) & ((unsigned)ix < (unsigned)p.IW));
-                const unsigned real = b_base[i] + (unsigned)(iy * (int)p.xs_h + ix * (int)p.xs_w + chunk * 64) * 2u;
-                const unsigned off = (real & okm) | (SBG_OOB_OFFSET & ~okm);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(st + (wave * IB + i) * 1024), 16, off, 0, 0, 0);
+                unsigned off = x_off[i];
+                if (ragged) off = (chunk * 64 + src_k < p.Cin) ? off : SBG_OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(st + (wave * IB + i) * 1024), 16, off, chunk * 128, 0, 0);
             }
         };
         auto read_b = [&](int stage) {
