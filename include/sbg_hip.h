@@ -202,6 +202,22 @@ int sbg_dot_hw(const void* u, const void* v, float* partial, int dtype, int layo
  * sync_batchnorm/batchnorm.py:71-79: `input_sum`, `input_ssum`).  r: fp32 [2, N*C]. */
 int sbg_moments_hw(const void* x, float* r, int dtype, int N, int C, int64_t HW, sbg_stream_t stream);
 
+/* Many small fp32 matrix products in one launch (csrc/grouped_gemm.hip): the per-layer affine maps of a synthesis network
+ * (train_parts/generators.py:333 `styles = self.affine(w)` in every SynthesisLayer / ToRGBLayer; FullyConnectedLayer.forward :117-131:
+ * `torch.addmm(b.unsqueeze(0), x, w.t())` with the gains folded in) and their gradients -- ~20 + ~60 separate GEMM / reduction launches per
+ * pass in the reference.  Problem p:  C[m][n] = sum_{t < nterms} alpha_t * sum_k A_t[m][k] B_t[k][n]  (+ bias[n] * bias_scale),
+ * every operand addressed by element strides (row stride, column stride), so transposes and slices of larger tensors cost nothing;
+ * `rowsum` (optional): rowsum[m] = rowsum_scale * sum_k A_0[m][k]  (the bias gradient next to the weight gradient).
+ * fp32, fixed summation order (ascending k, term 0 then term 1).  Outputs of different problems must not overlap. */
+typedef struct sbg_gg_problem {
+    const float *a0, *b0, *a1, *b1;         /* term 1 is ignored when nterms == 1 */
+    float* c; const float* bias; float* rowsum;
+    int64_t a0_rs, a0_cs, b0_rs, b0_cs, a1_rs, a1_cs, b1_rs, b1_cs, c_rs, c_cs;
+    int M, N, K0, K1, nterms;
+    float alpha0, alpha1, bias_scale, rowsum_scale;
+} sbg_gg_problem;
+int sbg_grouped_gemm(const sbg_gg_problem* problems, int count, sbg_stream_t stream);
+
 /* Both gradients of y = x * a[n, c] (the style modulation in front of a convolution, train_parts/generators.py:79; autograd's
  * `dy * a` and `(dy * x).sum([2, 3])`) in ONE pass over u = dy and v = x, channel-minor tensors with C / 8 dividing 256:
  *   y[n,p,c] = u[n,p,c] * scale[n*C + c]     and     partial[s][n*C + c] as sbg_dot_hw(u, v). */
@@ -377,7 +393,8 @@ int sbg_filter1d_batch(const float* x, const float* taps, float* y, int M, int H
  * (or the number pending when out == NULL). */
 enum sbg_kernel_kind {
     SBG_K_BIAS_ACT = 1, SBG_K_UPFIRDN2D = 2, SBG_K_CONV_IGEMM = 3, SBG_K_CONV_WGRAD = 4, SBG_K_WGRAD_REDUCE = 5,
-    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13, SBG_K_WEIGHT_PREP = 14, SBG_K_TORGB = 15, SBG_K_FROMRGB = 16
+    SBG_K_SCALE_NC = 6, SBG_K_DOT_HW = 7, SBG_K_SN_POWER = 9, SBG_K_ATTENTION = 10, SBG_K_GRID_SAMPLE = 11, SBG_K_FILTER1D = 12, SBG_K_COLOR = 13, SBG_K_WEIGHT_PREP = 14, SBG_K_TORGB = 15, SBG_K_FROMRGB = 16,
+    SBG_K_GROUPED_GEMM = 17
 };
 typedef struct sbg_prof_record {
     int    kind;            /* enum sbg_kernel_kind */

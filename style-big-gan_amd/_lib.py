@@ -87,13 +87,24 @@ class GridSampleParams(ctypes.Structure):
     ]
 
 
+class GgProblem(ctypes.Structure):
+    """sbg_gg_problem (include/sbg_hip.h): C = sum_t alpha_t A_t B_t (+ bias * bias_scale), strides in elements"""
+    _fields_ = [("a0", ctypes.c_void_p), ("b0", ctypes.c_void_p), ("a1", ctypes.c_void_p), ("b1", ctypes.c_void_p),
+                ("c", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("rowsum", ctypes.c_void_p),
+                ("a0_rs", ctypes.c_int64), ("a0_cs", ctypes.c_int64), ("b0_rs", ctypes.c_int64), ("b0_cs", ctypes.c_int64),
+                ("a1_rs", ctypes.c_int64), ("a1_cs", ctypes.c_int64), ("b1_rs", ctypes.c_int64), ("b1_cs", ctypes.c_int64),
+                ("c_rs", ctypes.c_int64), ("c_cs", ctypes.c_int64),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K0", ctypes.c_int), ("K1", ctypes.c_int), ("nterms", ctypes.c_int),
+                ("alpha0", ctypes.c_float), ("alpha1", ctypes.c_float), ("bias_scale", ctypes.c_float), ("rowsum_scale", ctypes.c_float)]
+
+
 class ProfRecord(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("dims", ctypes.c_int * 7), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
                 ("ms", ctypes.c_float), ("pad", ctypes.c_int)]
 
 
 KERNEL_KINDS = {1: "bias_act", 2: "upfirdn2d", 3: "conv_igemm", 4: "conv_wgrad", 5: "wgrad_reduce", 6: "scale_nc", 7: "dot_hw", 9: "sn_power", 10: "attention",
-                11: "grid_sample", 12: "filter1d", 13: "color", 14: "weight_prep", 15: "torgb", 16: "fromrgb"}
+                11: "grid_sample", 12: "filter1d", 13: "color", 14: "weight_prep", 15: "torgb", 16: "fromrgb", 17: "grouped_gemm"}
 
 _lib = None
 _lock = threading.Lock()
@@ -131,6 +142,7 @@ SYMBOLS = [
     ("sbg_dot_hw_splits", _c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int64]),
     ("sbg_dot_hw", _c.c_int, [_c.c_void_p] * 3 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_moments_hw", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
+    ("sbg_grouped_gemm", _c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p]),
     ("sbg_dot_hw_scale_supported", _c.c_int, [_c.c_int]),
     ("sbg_dot_hw_scale", _c.c_int, [_c.c_void_p] * 5 + [_c.c_int, _c.c_int, _c.c_int, _c.c_int64, _c.c_void_p]),
     ("sbg_modconv_bwd_supported", _c.c_int, [_c.c_int]),

@@ -344,7 +344,7 @@ class Discriminator(torch.nn.Module):
                 for res in self.block_resolutions[:lead]:
                     xp, part = getattr(self, f'b{res}')(xp, part, **block_kwargs)
                 parts.append(xp)
-            x, img = torch.cat(parts), None
+            x, img = misc.cat0(parts), None
         for res in self.block_resolutions[lead:]:
             x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
         cmap = self.mapping(None, c) if (self.c_dim is not None and self.c_dim > 0) else None

@@ -22,12 +22,13 @@ import torch
 
 from .. import utils
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, conv_bias_act, modconv, modulate, torgb, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, conv_bias_act, grouped_gemm, modconv, modulate, torgb, upfirdn2d
 
 generators = utils.ClassRegistry()
 
 LOW_PRECISION = torch.bfloat16
 import os as _os
+style_bank_enabled = _os.environ.get('SBG_STYLE_BANK', '1') != '0'   # the styles of all layers of a pass from one launch (SynthesisNetwork._style_bank)
 premodulate = _os.environ.get('SBG_PREMODULATE', '1') != '0'     # inference passes: conv0's tail applies conv1's style modulation (SynthesisBlock.forward)
 
 
@@ -393,8 +394,10 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
+    def forward(self, x, w, fused_modconv=True, styles=None):
+        """`styles` (extension): this layer's `affine(w) * weight_gain`, when the network has evaluated the affine maps of the whole pass at once"""
+        if styles is None:
+            styles = self.affine(w) * self.weight_gain
         if torgb.usable(x, self.weight):        # first-order passes: x streams once through per-sample weights (ops/torgb.py); fp32 planar result
             wmod = self.weight.reshape(1, self.weight.shape[0], -1) * styles.to(torch.float32).unsqueeze(1)
             return torgb.torgb(x, wmod, self.bias, clamp=self.conv_clamp)
@@ -464,7 +467,9 @@ class SynthesisBlock(torch.nn.Module):
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2,
                                     resample_filter=resample_filter, channels_last=self.channels_last)
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, **layer_kwargs):
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, styles=None, **layer_kwargs):
+        """`styles` (extension): (conv0's, conv1's, torgb's) styles or None each, from SynthesisNetwork's one-launch style bank"""
+        s0, s1, srgb = styles if styles is not None else (None, None, None)
         misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
         w_iter = iter(ws.unbind(dim=1))
         reduced = self.use_fp16 and not force_fp32
@@ -490,13 +495,13 @@ class SynthesisBlock(torch.nn.Module):
         if sole and premodulate and self.conv1.premodulated_input_ok(dtype, x.device, records_graph):
             # inference pass: conv0's last kernel hands conv1 its input already multiplied by conv1's styles (no `x * styles` pass in between)
             w0, w1 = next(w_iter), next(w_iter)
-            styles1 = self.conv1.affine(w1)
-            x = self.conv0(x, w0, post_scale=styles1, **lk)
+            styles1 = self.conv1.affine(w1) if s1 is None else s1
+            x = self.conv0(x, w0, post_scale=styles1, styles=s0, **lk)
             x = self.conv1(x, w1, gain=g1, styles=styles1, x_premodulated=True, **lk)
         else:
             if not first:
-                x = self.conv0(x, next(w_iter), **lk)
-            x = self.conv1(x, next(w_iter), gain=g1, x_sole_consumer=sole, **lk)
+                x = self.conv0(x, next(w_iter), styles=s0, **lk)
+            x = self.conv1(x, next(w_iter), gain=g1, x_sole_consumer=sole, styles=s1, **lk)
         if residual:
             x = shortcut + x     # out of place: both summands are outputs of fused conv + activation ops, which keep them for their backward
         if self.attention is not None:
@@ -507,7 +512,7 @@ class SynthesisBlock(torch.nn.Module):
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            rgb = self.torgb(x, next(w_iter), fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            rgb = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, styles=srgb).to(dtype=torch.float32, memory_format=torch.contiguous_format)
             img = rgb if img is None else img.add_(rgb)
         assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img
@@ -561,17 +566,46 @@ class SynthesisNetwork(torch.nn.Module):
         plan = self.pass_plan(ws.shape[0]) if ws.shape[0] > 1 else None
         tail, chunk = plan if plan is not None else (0, ws.shape[0])
         head = len(self.block_resolutions) - tail
+        bank = self._style_bank(ws)       # {res: (conv0's, conv1's, torgb's styles)} from one launch, or None: every layer evaluates its own affine map
         for res, cur_ws in zip(self.block_resolutions[:head], per_block[:head]):
-            x, img = getattr(self, f'b{res}')(x, img, cur_ws, **block_kwargs)
+            x, img = getattr(self, f'b{res}')(x, img, cur_ws, styles=(bank[res] if bank else None), **block_kwargs)
         if tail > 0:        # the highest-resolution blocks over slices of the batch (pass_plan), their images concatenated
             imgs = []
             for i in range(0, ws.shape[0], chunk):
                 xc, ic = x.narrow(0, i, chunk), (img.narrow(0, i, chunk) if img is not None else None)
                 for res, cur_ws in zip(self.block_resolutions[head:], per_block[head:]):
-                    xc, ic = getattr(self, f'b{res}')(xc, ic, cur_ws.narrow(0, i, chunk), **block_kwargs)
+                    st = tuple(None if s is None else s.narrow(0, i, chunk) for s in bank[res]) if bank else None
+                    xc, ic = getattr(self, f'b{res}')(xc, ic, cur_ws.narrow(0, i, chunk), styles=st, **block_kwargs)
                 imgs.append(ic)
-            img = torch.cat(imgs)
+            img = misc.cat0(imgs)
         return img
+
+    def _style_bank(self, ws):
+        """every layer's styles of this pass from ONE launch (torch_utils/ops/grouped_gemm.py) instead of one addmm per layer (reference :333, :397), its
+        backward two launches instead of two GEMMs and a reduction per layer.  First-order passes and inference only (the switch the fused synthesis
+        layers obey: trainers turn it off for phases that differentiate twice); SBG_STYLE_BANK=0 restores the per-layer calls."""
+        if not (style_bank_enabled and ws.is_cuda and ws.dtype == torch.float32 and (modconv.enabled or not torch.is_grad_enabled())):
+            return None
+        layers, where, w_idx = [], [], 0
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            has0 = block.in_channels != 0
+            entries = [(block.conv0.affine, w_idx, 1.0) if has0 else None, (block.conv1.affine, w_idx + (1 if has0 else 0), 1.0),
+                       (block.torgb.affine, w_idx + block.num_conv, float(block.torgb.weight_gain)) if block.num_torgb else None]
+            for pos, e in enumerate(entries):
+                if e is None:
+                    continue
+                fc, slot, post = e
+                if fc.activation != 'linear' or fc.bias is None or fc.weight.dtype != torch.float32 or not fc.weight.is_contiguous():
+                    return None
+                layers.append((slot, fc.weight, fc.bias, float(fc.weight_gain) * post, float(fc.bias_gain) * post))
+                where.append((res, pos))
+            w_idx += block.num_conv
+        styles = grouped_gemm.style_bank(ws, layers)
+        bank = {res: [None, None, None] for res in self.block_resolutions}
+        for (res, pos), s in zip(where, styles):
+            bank[res][pos] = s
+        return {res: tuple(v) for res, v in bank.items()}
 
     pass_bytes_limit = 1 << 31      # the op layer addresses tensors below 2 GiB
 

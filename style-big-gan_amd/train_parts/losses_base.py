@@ -218,7 +218,7 @@ class LossBase:
         """logits of every batch in `imgs` from one discriminator pass over their concatenation arranged by `order` (see _d_order)"""
         if self.augment_pipe is not None:
             imgs = [self.augment_pipe(img) for img in imgs]
-        x = imgs[0] if len(imgs) == 1 else torch.cat([img.to(imgs[0].dtype) for img in imgs])
+        x = misc.cat0([img.to(imgs[0].dtype) for img in imgs])
         c = None if cs[0] is None else (cs[0] if len(cs) == 1 else torch.cat(cs))
         if order:
             x = x.index_select(0, order[0])

@@ -211,9 +211,14 @@ def test_rounds_in_one_pass_equal_separate_rounds(dev):
 
     real = torch.rand(16, 3, 32, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(21)) * 2 - 1
     was = trainers.merge_rounds
-    # fp32 networks: the two schedules are the same sums in another order (2e-3 of each tensor's largest gradient: the R1 phase differentiates
-    # twice through convolutions evaluated as split-bf16 products, and its smallest gradient tensors are sums with heavy cancellation); bf16
-    # from 4x4 up: the reorderings also move roundings of the 16-bit activations of two networks in a row
+    # fp32 networks: the two schedules are the same sums in another order.  Two bounds per phase: the relative L2 error over ALL of the phase's
+    # gradients (2e-3: the R1 phase differentiates twice through convolutions evaluated as split-bf16 products), and per tensor 10x that of its
+    # largest element -- one tensor may carry a KINK FLIP: the small layers' split-K factor depends on the batch, so a pre-activation within an
+    # ulp of zero can land on the other side of the leaky ReLU in the other schedule and move the gradients that pass through it by a finite
+    # amount.  (Seen when the styles' fp32 summation order changed: with the per-layer library products written into the style bank's views the
+    # schedules agree to 3e-7, with the bank's own order one activation of the second round flips and a [64, 64, 3, 3] gradient moves by 2.8e-3
+    # of its largest element; scratch/bank_diag3.py.)  A wrong group order, gain or accumulation is an O(1) error in every tensor.
+    # bf16 from 4x4 up: the reorderings also move roundings of the 16-bit activations of two networks in a row
     for nfp, tol in ((0, 2e-3), (8, 5e-2)):
         gk, dk = _sg2_kwargs(res=32, nfp=nfp)
         kw = dict(gen_kwargs=gk, disc_kwargs=dk, loss_arch_kwargs=dict(style_mixing_prob=0), dis_regs=[("r1", dict(r1_gamma=0.1))], g_reg_interval=4,
@@ -244,11 +249,38 @@ def test_rounds_in_one_pass_equal_separate_rounds(dev):
         assert set(ga) == set(gb) >= {'Gmain', 'Dmain', 'Dreg'}     # (main and lazy-regulariser slots share an optimizer: a step records under both names)
         for name in gb:
             assert len(ga[name]) == len(gb[name]) > 0
+            num = sum(float((a.double() - b.double()).square().sum()) for a, b in zip(ga[name], gb[name])) ** 0.5
+            den = sum(float(b.double().square().sum()) for b in gb[name]) ** 0.5
+            # (the generator's phase runs before any optimizer step; the discriminator's phases see the generator AFTER its first Adam step, which turns
+            # a flipped gradient element into a full learning-rate step of that weight: their bound is the looser one)
+            assert num <= (tol if name in ('Gmain', 'Greg') else 5 * tol) * den, (nfp, name, num, den)
             for a, b in zip(ga[name], gb[name]):
                 # (absolute floor: R1's gradient w.r.t. a bias of a piecewise-linear network is zero up to rounding -- such tensors are ~1e-7 of noise)
-                assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-6, (nfp, name, tuple(b.shape), float((a - b).abs().max()), float(b.abs().max()))
+                assert float((a - b).abs().max()) <= 10 * tol * float(b.abs().max()) + 1e-6, (nfp, name, tuple(b.shape), float((a - b).abs().max()), float(b.abs().max()))
 
     gk2, dk2 = _sg2_kwargs(res=32, attn_g=(16,))                         # power iterations in G's attention block: rounds stay apart
     eng = trainers.StepEngine(dev, seed=5, gen_kwargs=gk2, disc_kwargs=dk2, loss_arch_kwargs=dict(style_mixing_prob=0), batch=16, batch_gpu=8)
     assert not any(eng._rounds_in_one_pass(p.name, 2) for p in eng.phases)
     eng.close()
+
+
+def test_cat0_is_cat_with_views_backward(dev):
+    """torch_utils.misc.cat0 (slice copies into one allocation; what the merged discriminator pass concatenates its batches with) == torch.cat,
+    for channel-minor and planar inputs, first and second derivatives."""
+    from style_big_gan_amd.torch_utils import misc
+    torch.manual_seed(0)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        a = torch.randn(3, 5, 8, 8, device=dev).to(memory_format=fmt).requires_grad_(True)
+        b = torch.randn(2, 5, 8, 8, device=dev).to(memory_format=fmt).requires_grad_(True)
+        y, y_ref = misc.cat0([a, b]), torch.cat([a, b])
+        assert torch.equal(y, y_ref) and y.is_contiguous(memory_format=fmt)
+        wgt = torch.randn_like(y_ref)
+        ga, gb = torch.autograd.grad((y.square() * wgt).sum(), [a, b], create_graph=True)
+        ra, rb = torch.autograd.grad((y_ref.square() * wgt).sum(), [a, b], create_graph=True)
+        assert torch.equal(ga, ra) and torch.equal(gb, rb)
+        (g2,) = torch.autograd.grad(ga.sum() + gb.sum(), [a])
+        (r2,) = torch.autograd.grad(ra.sum() + rb.sum(), [a])
+        assert torch.equal(g2, r2)
+    assert misc.cat0([a]) is a
+    mixed = misc.cat0([a, b.to(torch.bfloat16)])          # dtypes differ: plain torch.cat semantics (type promotion)
+    assert mixed.dtype == torch.float32

@@ -789,3 +789,77 @@ def test_fused_conv_bias_act_second_order_vs_oracle(dev):
         check(gd[0], gr[0].float(), 3e-2, f"fused d2w (stride {stride}, clamp {clamp})")
         if gr[1] is not None and float(gr[1].abs().max()) > 0:
             check(gd[1] if gd[1] is not None else torch.zeros_like(bd), gr[1].float(), 3e-2, f"fused d2b (stride {stride}, clamp {clamp})")
+
+
+def test_grouped_gemm_against_torch(dev):
+    """sbg_grouped_gemm (csrc/grouped_gemm.hip): a table of small fp32 products in one launch -- transposed and sliced operands by strides, one and two
+    terms, bias, row sums, ragged sizes, more problems than one launch's table holds (16) -- against torch.matmul in fp64."""
+    from style_big_gan_amd.torch_utils.ops import grouped_gemm
+    torch.manual_seed(0)
+    probs, refs = [], []
+    big = torch.randn(70, 9, 96, device=dev)
+    for i in range(37):
+        m, n, k = [(64, 128, 512), (70, 33, 96), (1, 512, 17), (130, 5, 64), (16, 64, 1)][i % 5]
+        a = torch.randn(m, k, device=dev) if i % 3 else torch.randn(k, m, device=dev).t()
+        b = torch.randn(k, n, device=dev) if i % 2 else torch.randn(n, k, device=dev).t()
+        if (m, k) == (70, 96):
+            a = big[:, i % 9]                                        # a slice of a [N, L, D] tensor (row stride L * D)
+        terms, ref = [(a, b, 0.37)], 0.37 * (a.double() @ b.double())
+        if i % 4 == 1:
+            k2 = 40
+            a2, b2 = torch.randn(m, k2, device=dev), torch.randn(k2, n, device=dev)
+            terms.append((a2, b2, -1.5)); ref = ref - 1.5 * (a2.double() @ b2.double())
+        c = torch.full([m, n + 3], float('nan'), device=dev)[:, 1:n + 1] if i % 5 == 2 else torch.full([m, n], float('nan'), device=dev)
+        pr = dict(c=c, terms=terms)
+        if i % 2 == 0:
+            pr['bias'] = torch.randn(n, device=dev); pr['bias_scale'] = 0.5
+            ref = ref + 0.5 * pr['bias'].double()
+        rs_ref = None
+        if i % 3 == 0:
+            pr['rowsum'] = torch.full([m], float('nan'), device=dev); pr['rowsum_scale'] = 2.0
+            rs_ref = 2.0 * a.double().sum(1)
+        probs.append(pr); refs.append((ref, rs_ref))
+    grouped_gemm.launch(probs, dev)
+    for pr, (ref, rs_ref) in zip(probs, refs):
+        tol = 1e-5 * max(1.0, float(ref.abs().max()))
+        assert float((pr['c'].double() - ref).abs().max()) < tol
+        if rs_ref is not None:
+            assert float((pr['rowsum'].double() - rs_ref).abs().max()) < 1e-5 * max(1.0, float(rs_ref.abs().max()))
+    grouped_gemm.launch([], dev)
+
+
+@pytest.mark.parametrize("nfp", [0, 2])
+def test_style_bank_equals_per_layer_affines(dev, nfp):
+    """SynthesisNetwork._style_bank (every layer's styles of a pass from one launch, backward from two) against the per-layer FullyConnectedLayer calls it
+    replaces (reference generators.py:333, 397): image, gradient of ws and of every affine weight / bias, in a first-order training pass and in inference."""
+    from style_big_gan_amd.train_parts import generators
+    torch.manual_seed(1)
+    syn = generators.SynthesisNetwork(w_dim=64, img_resolution=32, img_channels=3, channel_base=1024, channel_max=64, num_fp16_res=nfp,
+                                      block_kwargs=generators.Synthblockkwargs(conv_clamp=256)).to(dev)
+    for p in syn.parameters():
+        if p.ndim == 0:
+            torch.nn.init.constant_(p, 0.3)        # noise strengths off zero
+    ws = torch.randn(6, syn.num_ws, 64, device=dev, requires_grad=True)
+    results = []
+    for on in (False, True):
+        generators.style_bank_enabled = on
+        try:
+            syn.zero_grad(set_to_none=True); ws.grad = None
+            torch.manual_seed(7)
+            img = syn(ws, noise_mode='const')
+            (img * torch.linspace(-1, 1, img.numel(), device=dev).view_as(img)).sum().backward()
+            grads = {n: p.grad.clone() for n, p in syn.named_parameters() if 'affine' in n}
+            with torch.no_grad():
+                img_inf = syn(ws.detach(), noise_mode='const')
+            results.append((img.detach(), ws.grad.clone(), grads, img_inf))
+        finally:
+            generators.style_bank_enabled = True
+    (i0, g0, p0, f0), (i1, g1, p1, f1) = results
+    def close(a, b, what):
+        # fp32 network: the two fp32 summation orders; with bf16 blocks downstream a last-bit difference of a style can move a bf16 rounding
+        tol = (2e-4 if nfp == 0 else 3e-2) * max(1e-3, float(a.abs().max()))
+        assert float((a - b).abs().max()) <= tol, (what, float((a - b).abs().max()), tol)
+    close(i0, i1, 'image'); close(f0, f1, 'inference image'); close(g0, g1, 'd ws')
+    assert len(p0) == len(p1) >= 2 * 8
+    for n in p0:
+        close(p0[n], p1[n], n)
