@@ -734,7 +734,13 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ld_kernel(ConvArgs p, unsign
         });
         par ^= 1;
         if (++chunk < kchunks) continue;
-        pend = true; done = cur; done_par = tpar; tpar ^= 1;
+        done = cur; done_par = tpar; tpar ^= 1;
+        // X defers its epilogue behind the next step's B_a (Y is then in its last MFMA phase).  With a fused tail (its arithmetic makes the epilogue
+        // ~40 % longer) Y runs its own right away, behind its last MFMA, in the interval in which X runs X's: the two groups' tail arithmetic and
+        // stores side by side take less than one after the other (deferred like X's, Y's epilogue filled a second ~3850-cycle interval while X
+        // waited at the next barrier; scratch/halo_stamps.py).  Measured, interleaved rounds: with tail +3 / +1.7 / +1 % (128 / 256 / 512 channels),
+        // plain stores -1 % -- a plain launch keeps both deferred.
+        if (grpY && p.lds_params) epilogue(done); else pend = true;
         chunk = 0; tile += G;
         if (tile < ntiles) cur = advance(cur);
     }
