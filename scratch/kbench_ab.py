@@ -21,7 +21,10 @@ def ab(tag, fn, variants, kind, rounds=5, reps=4):
             if rnd == 0:
                 y = y.float() if torch.is_tensor(y) else y
                 if ref is None: ref = y
-                elif torch.is_tensor(y) and not (v & 512): assert torch.equal(ref, y), f'{tag}: variant {v} changes the result'
+                elif torch.is_tensor(y) and not (v & 512):      # (a variant may sum the taps in another order: last-bit differences of the 16-bit result)
+                    err = float((ref - y).abs().max()) / float(ref.abs().max())
+                    assert err < 2.0 ** -6, f'{tag}: variant {v} changes the result ({err:.3e} of the largest element)'
+                    if err: print(f'{tag}: variant {v} differs from the first by {err:.2e} of the largest element', flush=True)
                 continue
             torch.cuda.synchronize(); _lib.prof_enable(True); _lib.prof_fetch()
             for _ in range(reps): fn()
