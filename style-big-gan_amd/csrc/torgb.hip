@@ -24,7 +24,9 @@ struct RgbArgs {
     int blocks_per_n;
 };
 
-template <class T>
+// NO = outputs the instantiation carries (3: the RGB case without the padding row -- a quarter of the kernel's vector instructions; it is
+// issue-bound: ~100 vector instructions per KiB read)
+template <class T, int NO>
 __global__ void __launch_bounds__(256) torgb_fwd_kernel(RgbArgs p)
 {
     const int lpp = p.C >> 3;                       // lanes per pixel
@@ -32,9 +34,9 @@ __global__ void __launch_bounds__(256) torgb_fwd_kernel(RgbArgs p)
     const int n = blockIdx.x / p.blocks_per_n, blk = blockIdx.x % p.blocks_per_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = lane & (lpp - 1), pl = lane / lpp;
-    float w[MAX_O][8];
+    float w[NO][8];
 #pragma unroll
-    for (int o = 0; o < MAX_O; o++)
+    for (int o = 0; o < NO; o++)
 #pragma unroll
         for (int j = 0; j < 8; j++) w[o][j] = o < p.O ? p.wmod[((int64_t)n * p.O + o) * p.C + cl * 8 + j] : 0.0f;
     const T* xb = (const T*)p.x + (int64_t)n * p.HW * p.C;
@@ -43,18 +45,18 @@ __global__ void __launch_bounds__(256) torgb_fwd_kernel(RgbArgs p)
     const int64_t stride = (int64_t)p.blocks_per_n * 4 * ppw;
     for (int64_t pix0 = ((int64_t)blk * 4 + wave) * ppw; pix0 < p.HW; pix0 += stride) {
         const int64_t pix = pix0 + pl;
-        float acc[MAX_O] = {0.f, 0.f, 0.f, 0.f};
+        float acc[NO] = {};
         if (pix < p.HW) {
             float v[8];
             Vec8<T>::ld(xb + pix * p.C + cl * 8, v);
 #pragma unroll
-            for (int o = 0; o < MAX_O; o++)
+            for (int o = 0; o < NO; o++)
 #pragma unroll
                 for (int j = 0; j < 8; j++) acc[o] += v[j] * w[o][j];
         }
         if (lpp >= 16) {            // sum over the 16 lanes of a row with DPP rotates (no LDS crossbar), then across rows if a pixel spans several
 #pragma unroll
-            for (int o = 0; o < MAX_O; o++) {
+            for (int o = 0; o < NO; o++) {
                 float a = acc[o];
                 a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false));    // row_ror:8
                 a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x124, 0xf, 0xf, false));    // row_ror:4
@@ -64,20 +66,93 @@ __global__ void __launch_bounds__(256) torgb_fwd_kernel(RgbArgs p)
             }
             for (int m = lpp >> 1; m >= 16; m >>= 1)
 #pragma unroll
-                for (int o = 0; o < MAX_O; o++) acc[o] += __shfl_xor(acc[o], m, 64);
+                for (int o = 0; o < NO; o++) acc[o] += __shfl_xor(acc[o], m, 64);
         } else {
             for (int m = lpp >> 1; m >= 1; m >>= 1)
 #pragma unroll
-                for (int o = 0; o < MAX_O; o++) acc[o] += __shfl_xor(acc[o], m, 64);
+                for (int o = 0; o < NO; o++) acc[o] += __shfl_xor(acc[o], m, 64);
         }
         if (cl == 0 && pix < p.HW) {
 #pragma unroll
-            for (int o = 0; o < MAX_O; o++)
+            for (int o = 0; o < NO; o++)
                 if (o < p.O) {
                     float r = acc[o] + (p.bias ? p.bias[o] : 0.0f);
                     if (p.clamp >= 0.0f) r = fminf(fmaxf(r, -p.clamp), p.clamp);
                     yb[(int64_t)o * p.HW + pix] = r;
                 }
+        }
+    }
+}
+
+// Forward on the matrix cores after all -- not for the arithmetic (3 useful columns of 16) but because the streaming form above is ISSUE-bound:
+// ~100 vector instructions per KiB read (8 conversions, 24-32 FMAs, a 16-lane DPP reduction per output) hold it at 2.2-3.1 TB/s whatever is done to
+// the loads (two in flight per wave: slower; a contiguous run per workgroup: the same; one output row less: +2 %).  Here a wave takes 16 pixels:
+// lane (pixel fr, k-group fg) loads its 16 B straight into the A operand of v_mfma_f32_16x16x32 (no conversion, no reduction), the per-sample
+// weights sit in registers as the B operand -- split into three 16-bit parts (head, remainder, remainder of that), three MFMAs per 32 channels, so
+// the product keeps the fp32 weights' accuracy (two parts, ~2^-17, miss the 1e-5 the test holds the output to) -- and lanes fr < O hold the results
+// of pixels 4 fg .. 4 fg + 3 as one 16-B store.  C = 32 NKB = 128 / 256 (at 512 the 192 weight registers leave no room: the streaming kernel stays,
+// its launches are the small 4x4 .. 64x64 layers), HW a multiple of 16.
+// Measured ([64, C, R, R], same box): 128 @256^2 369 -> 253 us (3.05 -> 4.44 TB/s), 256 @128^2 207 -> 143 us (2.66 -> 3.83).
+template <class T> struct RgbMfma;
+template <> struct RgbMfma<bf16_s> {
+    static __device__ __forceinline__ unsigned short cvt(float v) { return f32_to_bf16_bits(v); }
+    static __device__ __forceinline__ float back(unsigned short b) { return bf16_bits_to_f32(b); }
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct RgbMfma<f16_s> {
+    static __device__ __forceinline__ unsigned short cvt(float v) { return f32_to_f16_bits(v); }
+    static __device__ __forceinline__ float back(unsigned short b) { return f16_bits_to_f32(b); }
+    static __device__ __forceinline__ float4_t run(short8_t a, short8_t b, float4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+template <class T, int NKB>
+__global__ void __launch_bounds__(256) torgb_fwd_mfma_kernel(RgbArgs p)
+{
+    const int n = blockIdx.x / p.blocks_per_n, blk = blockIdx.x % p.blocks_per_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+    short8_t bh[NKB], bm[NKB], bl[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float w = fr < p.O ? p.wmod[((int64_t)n * p.O + fr) * p.C + kb * 32 + fg * 8 + j] : 0.0f;
+            const unsigned short h = RgbMfma<T>::cvt(w);
+            const float r1 = w - RgbMfma<T>::back(h);
+            const unsigned short m = RgbMfma<T>::cvt(r1);
+            bh[kb][j] = (short)h; bm[kb][j] = (short)m;
+            bl[kb][j] = (short)RgbMfma<T>::cvt(r1 - RgbMfma<T>::back(m));
+        }
+    const float bias = (p.bias && fr < p.O) ? p.bias[fr] : 0.0f;
+    const T* xb = (const T*)p.x + (int64_t)n * p.HW * p.C;
+    float* yb = p.y + (int64_t)n * p.O * p.HW;
+    const int64_t groups = p.HW >> 4;
+    const int64_t per = (groups + p.blocks_per_n - 1) / p.blocks_per_n;      // a workgroup streams one contiguous run of 16-pixel groups
+    const int64_t gend = (blk + 1) * per < groups ? (blk + 1) * per : groups;
+    for (int64_t g = blk * per + wave; g < gend; g += 4) {
+        const T* px = xb + (g * 16 + fr) * p.C + fg * 8;
+        short8_t a[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) a[kb] = *reinterpret_cast<const short8_t*>(px + kb * 32);
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) {
+            acc = RgbMfma<T>::run(a[kb], bl[kb], acc);      // smallest parts first
+            acc = RgbMfma<T>::run(a[kb], bm[kb], acc);
+            acc = RgbMfma<T>::run(a[kb], bh[kb], acc);
+        }
+        if (fr < p.O) {
+            float4_t r;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float v = acc[e] + bias;
+                if (p.clamp >= 0.0f) v = fminf(fmaxf(v, -p.clamp), p.clamp);
+                r[e] = v;
+            }
+            *reinterpret_cast<float4_t*>(yb + (int64_t)fr * p.HW + g * 16 + 4 * fg) = r;
         }
     }
 }
@@ -224,8 +299,25 @@ extern "C" int sbg_torgb_fwd(const void* x, const float* wmod, const float* bias
     hipStream_t stream = (hipStream_t)stream_;
     SbgProfScope prof(stream, SBG_K_TORGB, 2.0 * N * O * (double)C * HW, (double)N * HW * (2.0 * C + 4.0 * O), {N, C, O, (int)HW, 0, 0, 0});
     dim3 grid((unsigned)(N * a.blocks_per_n)), block(256);
-    if (dtype == SBG_BF16) SBG_LAUNCH(torgb_fwd_kernel<bf16_s>, grid, block, 0, stream, a);
-    else                   SBG_LAUNCH(torgb_fwd_kernel<f16_s>, grid, block, 0, stream, a);
+    static const char* emf = sbg_env("SBG_TORGB_MFMA");          // experiment switch: 0 = the streaming kernel for every shape
+    if ((HW & 15) == 0 && (C == 128 || C == 256) && sbg_aligned16(x) && sbg_aligned16(y) && !(emf && atoi(emf) == 0)) {
+        if (dtype == SBG_BF16) {
+            if (C == 128) SBG_LAUNCH((torgb_fwd_mfma_kernel<bf16_s, 4>), grid, block, 0, stream, a);
+            else SBG_LAUNCH((torgb_fwd_mfma_kernel<bf16_s, 8>), grid, block, 0, stream, a);
+        } else {
+            if (C == 128) SBG_LAUNCH((torgb_fwd_mfma_kernel<f16_s, 4>), grid, block, 0, stream, a);
+            else SBG_LAUNCH((torgb_fwd_mfma_kernel<f16_s, 8>), grid, block, 0, stream, a);
+        }
+        SBG_HIP_LAUNCH_CHECK();
+        return 0;
+    }
+    if (O <= 3) {
+        if (dtype == SBG_BF16) SBG_LAUNCH((torgb_fwd_kernel<bf16_s, 3>), grid, block, 0, stream, a);
+        else                   SBG_LAUNCH((torgb_fwd_kernel<f16_s, 3>), grid, block, 0, stream, a);
+    } else {
+        if (dtype == SBG_BF16) SBG_LAUNCH((torgb_fwd_kernel<bf16_s, MAX_O>), grid, block, 0, stream, a);
+        else                   SBG_LAUNCH((torgb_fwd_kernel<f16_s, MAX_O>), grid, block, 0, stream, a);
+    }
     SBG_HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -611,7 +611,8 @@ def test_torgb_streaming_kernels(dev):
     """ops/torgb.py vs the fp64 composition clamp(conv1x1(x * s, w) + b): output, dx, d wmod (-> dw, ds), db; clamp mask; ragged pixel counts"""
     from style_big_gan_amd.torch_utils.ops import torgb
     torch.manual_seed(13)
-    for (n, c, o, h, w, clamp) in [(3, 128, 3, 16, 16, 0.8), (2, 512, 3, 8, 8, None), (2, 64, 3, 17, 13, 0.5), (4, 32, 1, 9, 9, 256.0), (2, 8, 4, 5, 7, None)]:
+    # (128 / 256 channels with a multiple of 16 pixels: the matrix-core forward, weights in three 16-bit parts; the others: the streaming kernel)
+    for (n, c, o, h, w, clamp) in [(3, 128, 3, 16, 16, 0.8), (2, 256, 3, 24, 32, 1.5), (2, 128, 2, 12, 20, None), (2, 512, 3, 8, 8, None), (2, 64, 3, 17, 13, 0.5), (4, 32, 1, 9, 9, 256.0), (2, 8, 4, 5, 7, None)]:
         x = torch.randn(n, c, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         wt = (torch.randn(o, c, 1, 1, device=dev) / c ** 0.5).requires_grad_(True)
         s = (torch.randn(n, c, device=dev) * 0.5 + 1).requires_grad_(True)
